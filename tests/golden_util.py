@@ -1,0 +1,27 @@
+"""Helpers shared by the parity tests: golden fixture loading and error metrics."""
+import glob
+import os
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN_DIR, name + ".npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def max_abs(a, b):
+    return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)))) if a.size else 0.0
+
+
+def scaled_err(a, b):
+    """max |a-b| / max(1, max|b|): the tolerance the tests quote for gradients."""
+    b64 = np.asarray(b, dtype=np.float64)
+    scale = max(1.0, float(np.max(np.abs(b64)))) if b64.size else 1.0
+    return max_abs(a, b) / scale
