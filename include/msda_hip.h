@@ -1,0 +1,108 @@
+/*
+ * include/msda_hip.h -- C ABI of libmsda_hip.so, the MI355X (gfx950) implementation of
+ * UNINEXT's MultiScaleDeformableAttention operator.
+ *
+ * This is the drop-in boundary: the entry points below are what the reference's pybind
+ * module `MultiScaleDeformableAttention` (ops/src/vision.cpp:13-16) would bind instead of
+ * its CUDA implementation.  ops/ = projects/UNINEXT/uninext/models/deformable_detr/ops/.
+ *
+ *   msda_hip_forward_{f32,f64}   replaces ms_deform_attn_cuda_forward
+ *                                (ops/src/cuda/ms_deform_attn_cuda.cu:20-80) and the kernel
+ *                                it launches (ops/src/cuda/ms_deform_im2col_cuda.cuh:237-299,
+ *                                923-954).
+ *   msda_hip_backward_{f32,f64}  replaces ms_deform_attn_cuda_backward
+ *                                (ops/src/cuda/ms_deform_attn_cuda.cu:83-153) and the
+ *                                col2im dispatcher + kernels (…cuda.cuh:301-920, 956-1327).
+ *
+ * Conventions
+ *   - Plain pointers and sizes only; no torch / ATen types.  All data pointers are DEVICE
+ *     pointers on the current HIP device, contiguous, row-major:
+ *       value  [batch, spatial_size, num_heads, channels]
+ *       spatial_shapes [num_levels, 2] int64 (H, W)       -- device memory, as in the reference
+ *       level_start_index [num_levels] int64              -- device memory
+ *       sampling_loc [batch, num_query, num_heads, num_levels, num_point, 2]  (x, y) in [0,1]
+ *       attn_weight  [batch, num_query, num_heads, num_levels, num_point]
+ *       output / grad_output [batch, num_query, num_heads*channels]
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).  Kernels
+ *     are only ENQUEUED on it: no allocation, no synchronisation, no host<->device copy,
+ *     so the calls are hipGraph-capturable (the reference launches on the current stream
+ *     the same way, ms_deform_attn_cuda.cu:65,135).
+ *   - Forward writes every element of `output` (no pre-zeroing needed; the reference's
+ *     at::zeros at ms_deform_attn_cuda.cu:54 is redundant).
+ *   - Backward OVERWRITES grad_sampling_loc and grad_attn_weight and ACCUMULATES into
+ *     grad_value with float atomics: the caller must zero grad_value first (the reference
+ *     does so with at::zeros_like, ms_deform_attn_cuda.cu:121).  Summation order of
+ *     grad_value is therefore not deterministic, exactly as in the reference.
+ *   - Return value: 0 on success, a negative MSDA_ERR_* for rejected arguments, a positive
+ *     hipError_t if the launch failed (the reference only printf()s launch errors,
+ *     ms_deform_im2col_cuda.cuh:948-952).  msda_hip_last_error() returns a thread-local
+ *     human-readable message for the last non-zero return.
+ *   - The whole batch is processed in one launch; the reference's im2col_step chunking
+ *     (ms_deform_attn_cuda.cu:50-52,61) has no numerical effect and is validated by the
+ *     Python binding only.
+ */
+#ifndef MSDA_HIP_H_
+#define MSDA_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSDA_HIP_ABI_VERSION 1
+
+#define MSDA_ERR_NULL_POINTER (-1)
+#define MSDA_ERR_BAD_DIMS (-2)      /* a dimension <= 0 (except batch/num_query == 0, which is a no-op) */
+#define MSDA_ERR_TOO_LARGE (-3)     /* a per-image extent does not fit the 32-bit offsets the kernels use */
+#define MSDA_ERR_BAD_VARIANT (-4)   /* MSDA_HIP_FWD_VARIANT / msda_hip_set_variant names an unknown kernel */
+
+int msda_hip_abi_version(void);
+const char* msda_hip_last_error(void);
+
+int msda_hip_forward_f32(const float* value, const int64_t* spatial_shapes,
+                         const int64_t* level_start_index, const float* sampling_loc,
+                         const float* attn_weight, int batch, int spatial_size, int num_heads,
+                         int channels, int num_levels, int num_query, int num_point,
+                         float* output, void* stream);
+
+int msda_hip_forward_f64(const double* value, const int64_t* spatial_shapes,
+                         const int64_t* level_start_index, const double* sampling_loc,
+                         const double* attn_weight, int batch, int spatial_size, int num_heads,
+                         int channels, int num_levels, int num_query, int num_point,
+                         double* output, void* stream);
+
+int msda_hip_backward_f32(const float* grad_output, const float* value,
+                          const int64_t* spatial_shapes, const int64_t* level_start_index,
+                          const float* sampling_loc, const float* attn_weight, int batch,
+                          int spatial_size, int num_heads, int channels, int num_levels,
+                          int num_query, int num_point, float* grad_value,
+                          float* grad_sampling_loc, float* grad_attn_weight, void* stream);
+
+int msda_hip_backward_f64(const double* grad_output, const double* value,
+                          const int64_t* spatial_shapes, const int64_t* level_start_index,
+                          const double* sampling_loc, const double* attn_weight, int batch,
+                          int spatial_size, int num_heads, int channels, int num_levels,
+                          int num_query, int num_point, double* grad_value,
+                          double* grad_sampling_loc, double* grad_attn_weight, void* stream);
+
+/*
+ * Kernel selection (tuning / A-B measurement only; results are identical up to fp32
+ * summation order).  which: 0 = forward, 1 = backward.  variant: 0 = automatic (default),
+ * 1 = generic one-thread-per-output kernel, 2 = lane-group gather kernel, higher numbers as
+ * listed by msda_hip_variant_name().  Returns 0 or MSDA_ERR_BAD_VARIANT.
+ */
+int msda_hip_set_variant(int which, int variant);
+int msda_hip_get_variant(int which);
+const char* msda_hip_variant_name(int which, int variant); /* NULL past the last variant */
+
+/*
+ * Name of the kernel the last forward (which = 0) / backward (which = 1) call on this
+ * thread actually launched -- lets tests assert that the intended HIP path ran.
+ */
+const char* msda_hip_last_kernel(int which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSDA_HIP_H_ */

@@ -1,0 +1,86 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/msda_hip.h declares.
+No compute call is made here (there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from uninext_amd import build, _lib
+    build.build()
+    return _lib.load()
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "msda_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(msda_hip_\w+)\s*\(", text)))
+
+
+def test_header_declares_the_boundary():
+    names = declared_functions()
+    for must in ("msda_hip_forward_f32", "msda_hip_forward_f64", "msda_hip_backward_f32", "msda_hip_backward_f64",
+                 "msda_hip_last_error", "msda_hip_abi_version"):
+        assert must in names
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from uninext_amd import _lib
+    names = declared_functions()
+    assert set(names) == set(_lib.EXPORTS)
+    for n in names:
+        assert hasattr(lib, n), n
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        getattr(raw, n)
+
+
+def test_abi_version_and_variant_table(lib):
+    from uninext_amd import _lib
+    assert lib.msda_hip_abi_version() == _lib.ABI_VERSION == 1
+    assert _lib.variants("forward")[:3] == ["auto", "msda_fwd_generic", "msda_fwd_lanegroup"]
+    assert _lib.variants("backward")[:3] == ["auto", "msda_bwd_generic", "msda_bwd_lanegroup"]
+    with pytest.raises(ValueError):
+        _lib.set_variant("forward", 99)
+    _lib.set_variant("forward", "msda_fwd_generic")
+    assert lib.msda_hip_get_variant(0) == 1
+    _lib.set_variant("forward", "auto")
+
+
+def test_argument_validation_without_gpu(lib):
+    """Rejected arguments return before any HIP call."""
+    i = ctypes.c_int
+    null = ctypes.c_void_p(0)
+    one = ctypes.c_void_p(16)
+    # batch == 0 / num_query == 0: success, nothing launched
+    assert lib.msda_hip_forward_f32(null, null, null, null, null, 0, 5, 1, 4, 1, 3, 1, null, null) == 0
+    assert lib.msda_hip_forward_f32(null, null, null, null, null, 2, 5, 1, 4, 1, 0, 1, null, null) == 0
+    assert lib.msda_hip_forward_f32(one, one, one, one, one, 1, 5, 0, 4, 1, 3, 1, one, null) == -2
+    assert b"must be > 0" in lib.msda_hip_last_error()
+    assert lib.msda_hip_forward_f32(null, one, one, one, one, 1, 5, 1, 4, 1, 3, 1, one, null) == -1
+    assert lib.msda_hip_backward_f64(one, one, one, one, one, null, 1, 5, 1, 4, 1, 3, 1, one, one, one, null) == -1
+
+
+def test_hip_objects_target_gfx950():
+    """The shipped code object is gfx950 only: no other offload arch, no fallback fat binary."""
+    from uninext_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    for other in (b"gfx942", b"gfx90a", b"sm_80"):
+        assert other not in blob
+
+
+def test_no_compat_layers_in_sources():
+    """north_star: no hipify output, no CUDA-compat headers, no dual CUDA/HIP dispatch."""
+    src_dir = os.path.join(ROOT, "uninext_amd", "csrc")
+    for name in os.listdir(src_dir):
+        if not name.endswith((".hip", ".hpp", ".h")):
+            continue
+        text = open(os.path.join(src_dir, name)).read()
+        for banned in ("cuda_runtime", "__HIP_PLATFORM", "THC", "hipify", "ATen", "torch/"):
+            assert banned not in text, (name, banned)

@@ -1,0 +1,100 @@
+"""CPU: host-side mirror of the reference interface (no GPU compute)."""
+import math
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cpu_tensors_are_rejected_like_the_reference():
+    """ops/src/ms_deform_attn.h:35-38: CPU input -> 'Not implemented on the CPU' (no silent fallback)."""
+    import MultiScaleDeformableAttention as MSDA
+    v = torch.zeros(1, 2, 1, 4)
+    args = (v, torch.tensor([[1, 2]]), torch.tensor([0]), torch.zeros(1, 1, 1, 1, 1, 2), torch.zeros(1, 1, 1, 1, 1))
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        MSDA.ms_deform_attn_forward(*args, 64)
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        MSDA.ms_deform_attn_backward(*args, torch.zeros(1, 1, 4), 64)
+
+
+def test_module_name_and_exports_match_the_reference_extension():
+    """ops/src/vision.cpp:13-16 exports exactly two functions under the module name the reference imports."""
+    import MultiScaleDeformableAttention as MSDA
+    assert MSDA.__name__ == "MultiScaleDeformableAttention"
+    assert sorted(MSDA.__all__) == ["ms_deform_attn_backward", "ms_deform_attn_forward"]
+
+
+def test_product_package_does_not_import_the_oracle():
+    """The oracle is test infrastructure: nothing under uninext_amd/ (or the drop-in module) may import it."""
+    import re
+    pkg = os.path.join(ROOT, "uninext_amd")
+    files = [os.path.join(ROOT, "MultiScaleDeformableAttention.py")]
+    for d, _, names in os.walk(pkg):
+        files += [os.path.join(d, n) for n in names if n.endswith(".py")]
+    for f in files:
+        text = open(f).read()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+        assert "grid_sample" not in text, f
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from uninext_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libmsda_hip.so")
+    with pytest.raises(RuntimeError, match="There is no fallback"):
+        _lib.load()
+
+
+def test_msdeformattn_constructor_and_init():
+    """ops/modules/ms_deform_attn.py:30-76: parameter names/shapes and the initial sampling pattern."""
+    from uninext_amd.modules import MSDeformAttn
+    m = MSDeformAttn(256, 4, 8, 4)
+    sd = m.state_dict()
+    assert {k: tuple(v.shape) for k, v in sd.items()} == {
+        "sampling_offsets.weight": (256, 256), "sampling_offsets.bias": (256,),
+        "attention_weights.weight": (128, 256), "attention_weights.bias": (128,),
+        "value_proj.weight": (256, 256), "value_proj.bias": (256,),
+        "output_proj.weight": (256, 256), "output_proj.bias": (256,)}
+    assert m.im2col_step == 64
+    assert float(sd["sampling_offsets.weight"].abs().max()) == 0.0
+    assert float(sd["attention_weights.weight"].abs().max()) == 0.0 and float(sd["attention_weights.bias"].abs().max()) == 0.0
+    bias = sd["sampling_offsets.bias"].view(8, 4, 4, 2)
+    for h in range(8):
+        th = h * 2 * math.pi / 8
+        d = torch.tensor([math.cos(th), math.sin(th)])
+        d = d / d.abs().max()
+        for p in range(4):
+            assert torch.allclose(bias[h, :, p], (d * (p + 1)).expand(4, 2), atol=1e-6)
+    with pytest.raises(ValueError, match="divisible"):
+        MSDeformAttn(250, 4, 8, 4)
+
+
+def test_msdeformattn_bad_reference_dim_raises():
+    """ops/modules/ms_deform_attn.py:110-112 -- checked before the op is reached, so it runs on CPU."""
+    from uninext_amd.modules import MSDeformAttn
+    m = MSDeformAttn(32, 1, 2, 1)
+    shapes = torch.tensor([[2, 3]])
+    with pytest.raises(ValueError, match="Last dim of reference_points"):
+        m(torch.zeros(1, 4, 32), torch.zeros(1, 4, 1, 3), torch.zeros(1, 6, 32), shapes, torch.tensor([0]))
+    with pytest.raises(AssertionError):
+        m(torch.zeros(1, 4, 32), torch.zeros(1, 4, 1, 2), torch.zeros(1, 5, 32), shapes, torch.tensor([0]))
+
+
+def test_workload_shapes_and_bytes():
+    from uninext_amd import workloads as w
+    assert sum(h * ww for h, ww in w.R50_LEVELS_INFER) == 22223
+    assert sum(h * ww for h, ww in w.R50_LEVELS_TRAIN) == 22323
+    x = w.make_inputs("encoder", "model", batch=1, levels=((5, 6), (3, 3)), device="cpu", seed=3)
+    assert x["value"].shape == (1, 39, 8, 32) and x["loc"].shape == (1, 39, 8, 2, 4, 2)
+    assert x["lsi"].tolist() == [0, 30]
+    assert torch.allclose(x["attn"].sum((-1, -2)), torch.ones(1, 39, 8))
+    y = w.make_inputs("encoder", "model", batch=1, levels=((5, 6), (3, 3)), device="cpu", seed=3)
+    assert torch.equal(x["loc"], y["loc"])
+    # 79.65 MB / image encoder forward, 25.06 MB decoder; 136.5 / 49.2 MB backward
+    assert abs(w.algorithmic_bytes_forward(1, 22223, 22223) / 1e6 - 79.65) < 0.01
+    assert abs(w.algorithmic_bytes_forward(1, 22223, 900) / 1e6 - 25.06) < 0.01
+    assert abs(w.algorithmic_bytes_backward(1, 22223, 22223) / 1e6 - 136.5) < 0.1
+    assert abs(w.algorithmic_bytes_backward(1, 22223, 900) / 1e6 - 49.2) < 0.01

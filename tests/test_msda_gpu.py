@@ -1,0 +1,413 @@
+"""GPU parity tests of the HIP MSDeformAttn path (run on the MI355X box: pytest -m gpu).
+
+Everything goes through the C ABI (uninext_amd.ext -> libmsda_hip.so).  The CPU oracle
+(oracle/msda_oracle.c, pinned to reference-minted fixtures by tests/test_oracle_golden.py) and the
+golden fixtures themselves are the checkers.  Tolerances: fp64 ~1e-12; fp32 forward 1e-4 abs
+(BASELINE.json north_star; the reference's own fp32 check is rtol 1e-2 / atol 1e-3, ops/test.py:56);
+fp32 gradients 1e-4 relative to the gradient scale (atomics => summation order differs run to run).
+"""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import golden_names, load_golden, max_abs, scaled_err
+
+pytestmark = pytest.mark.gpu
+
+NAMES = golden_names()
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def api():
+    import MultiScaleDeformableAttention as MSDA  # the name the reference imports (func.py:18)
+    from uninext_amd import _lib
+    _lib.load()  # fails loudly if libmsda_hip.so is not built
+    return MSDA, _lib
+
+
+def _to(g, dev, dtype):
+    f = lambda k: torch.from_numpy(g[k]).to(device=dev, dtype=dtype).contiguous()
+    i = lambda k: torch.from_numpy(g[k]).to(device=dev)
+    return f("value"), i("shapes"), i("lsi"), f("loc"), f("attn"), f("grad_out")
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------
+# golden fixtures (reference-generated)
+
+@pytest.mark.parametrize("name", NAMES)
+def test_golden_forward_f64(name, dev, api):
+    MSDA, lib = api
+    g = load_golden(name)
+    v, sh, lsi, loc, attn, _ = _to(g, dev, torch.float64)
+    out = MSDA.ms_deform_attn_forward(v, sh, lsi, loc, attn, 64)
+    assert lib.last_kernel("forward") == "msda_fwd_generic"
+    assert out.shape == g["out"].shape
+    assert max_abs(_np(out), g["out"]) < 1e-12
+
+
+@pytest.mark.parametrize("variant", ["auto", "msda_fwd_generic", "msda_fwd_lanegroup"])
+@pytest.mark.parametrize("name", NAMES)
+def test_golden_forward_f32(name, variant, dev, api):
+    MSDA, lib = api
+    g = load_golden(name)
+    v, sh, lsi, loc, attn, _ = _to(g, dev, torch.float32)
+    lib.set_variant("forward", variant)
+    try:
+        out = MSDA.ms_deform_attn_forward(v, sh, lsi, loc, attn, 64)
+    finally:
+        lib.set_variant("forward", "auto")
+    D = v.shape[3]
+    lanegroup_capable = D % 4 == 0 and (D // 4) & (D // 4 - 1) == 0
+    if variant != "msda_fwd_generic" and lanegroup_capable:
+        assert lib.last_kernel("forward") == "msda_fwd_lanegroup"
+    else:
+        assert lib.last_kernel("forward") == "msda_fwd_generic"
+    assert max_abs(_np(out), g["out"]) < 1e-4
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_golden_backward_f64(name, dev, api):
+    MSDA, lib = api
+    g = load_golden(name)
+    v, sh, lsi, loc, attn, go = _to(g, dev, torch.float64)
+    gv, gl, ga = MSDA.ms_deform_attn_backward(v, sh, lsi, loc, attn, go, 64)
+    assert lib.last_kernel("backward") == "msda_bwd_generic"
+    assert max_abs(_np(gv), g["grad_value"]) < 1e-11
+    assert max_abs(_np(ga), g["grad_attn"]) < 1e-11
+    if name != "border":  # one-sided derivative convention exactly on cell edges (see test_oracle_golden.py)
+        assert max_abs(_np(gl), g["grad_loc"]) < 1e-9
+
+
+@pytest.mark.parametrize("variant", ["auto", "msda_bwd_generic", "msda_bwd_lanegroup"])
+@pytest.mark.parametrize("name", NAMES)
+def test_golden_backward_f32(name, variant, dev, api):
+    MSDA, lib = api
+    g = load_golden(name)
+    v, sh, lsi, loc, attn, go = _to(g, dev, torch.float32)
+    lib.set_variant("backward", variant)
+    try:
+        gv, gl, ga = MSDA.ms_deform_attn_backward(v, sh, lsi, loc, attn, go, 64)
+    finally:
+        lib.set_variant("backward", "auto")
+    assert scaled_err(_np(gv), g["grad_value"]) < 1e-4
+    assert scaled_err(_np(ga), g["grad_attn"]) < 1e-4
+    if name != "border":
+        assert scaled_err(_np(gl), g["grad_loc"]) < 1e-3
+
+
+def test_border_fixture_backward_matches_c_oracle(dev, api):
+    """On cell edges the HIP kernels must follow the CUDA formula (as the C oracle does), fp64 exact."""
+    from oracle import msda_oracle
+    MSDA, _ = api
+    g = load_golden("border")
+    v, sh, lsi, loc, attn, go = _to(g, dev, torch.float64)
+    gv, gl, ga = MSDA.ms_deform_attn_backward(v, sh, lsi, loc, attn, go, 64)
+    ogv, ogl, oga = msda_oracle.backward(g["grad_out"], g["value"], g["shapes"], g["lsi"], g["loc"], g["attn"])
+    assert max_abs(_np(gv), ogv) < 1e-12 and max_abs(_np(gl), ogl) < 1e-11 and max_abs(_np(ga), oga) < 1e-12
+
+
+# ------------------------------------------------------------------------------------------------
+# seeded workloads vs the C oracle
+
+@pytest.mark.parametrize("flavour", ["model", "uniform"])
+@pytest.mark.parametrize("kind", ["encoder", "decoder"])
+def test_quarter_scale_r50_vs_oracle(kind, flavour, dev, api):
+    """R50 pyramid at 1/4 linear scale (S = 1394), M=8 D=32 L=4 P=4, N=2: forward + backward vs oracle."""
+    from oracle import msda_oracle
+    from uninext_amd import workloads
+    MSDA, lib = api
+    levels = ((25, 42), (13, 21), (7, 11), (4, 6))
+    x = workloads.make_inputs(kind, flavour, batch=2, levels=levels, num_query=None if kind == "encoder" else 300,
+                              seed=21, device=dev)
+    out = MSDA.ms_deform_attn_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], 64)
+    assert lib.last_kernel("forward") == "msda_fwd_lanegroup"
+    ref = msda_oracle.forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
+    assert max_abs(_np(out), ref) < 1e-4
+    go = torch.randn(out.shape, generator=torch.Generator().manual_seed(5)).to(dev)
+    gv, gl, ga = MSDA.ms_deform_attn_backward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], go, 64)
+    assert lib.last_kernel("backward") == "msda_bwd_lanegroup"
+    ogv, ogl, oga = msda_oracle.backward(go, x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
+    assert scaled_err(_np(gv), ogv) < 1e-4
+    assert scaled_err(_np(ga), oga) < 1e-4
+    assert scaled_err(_np(gl), ogl) < 1e-3
+
+
+@pytest.mark.parametrize("D,M,L,P", [(4, 3, 2, 3), (8, 5, 3, 2), (16, 2, 1, 5), (64, 2, 4, 4), (128, 1, 2, 2),
+                                     (256, 1, 2, 1), (32, 8, 4, 8), (32, 8, 5, 4)])
+def test_lanegroup_shapes_vs_oracle(D, M, L, P, dev, api):
+    """Every lane-group width G = D/4 in {1..64} and runtime L*P paths."""
+    from oracle import msda_oracle
+    MSDA, lib = api
+    g = torch.Generator().manual_seed(D * 131 + M)
+    levels = [(9, 7), (5, 4), (3, 3), (2, 2), (1, 2)][:L]
+    S = sum(h * w for h, w in levels)
+    N, Lq = 2, 53
+    value = torch.randn(N, S, M, D, generator=g).to(dev)
+    loc = (torch.rand(N, Lq, M, L, P, 2, generator=g) * 1.3 - 0.15).to(dev)
+    attn = torch.softmax(torch.randn(N, Lq, M, L * P, generator=g), -1).view(N, Lq, M, L, P).to(dev)
+    from uninext_amd.workloads import level_tensors
+    sh, lsi = level_tensors(levels, dev)
+    out = MSDA.ms_deform_attn_forward(value, sh, lsi, loc, attn, 64)
+    assert lib.last_kernel("forward") == "msda_fwd_lanegroup"
+    assert max_abs(_np(out), msda_oracle.forward(value, sh, lsi, loc, attn)) < 1e-4
+    go = torch.randn(out.shape, generator=g).to(dev)
+    gv, gl, ga = MSDA.ms_deform_attn_backward(value, sh, lsi, loc, attn, go, 64)
+    assert lib.last_kernel("backward") == "msda_bwd_lanegroup"
+    ogv, ogl, oga = msda_oracle.backward(go, value, sh, lsi, loc, attn)
+    assert scaled_err(_np(gv), ogv) < 1e-4 and scaled_err(_np(ga), oga) < 1e-4 and scaled_err(_np(gl), ogl) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------
+# full BASELINE sizes: oracle on a query subset + size-independent properties
+
+@pytest.mark.parametrize("flavour", ["model", "uniform"])
+def test_full_size_encoder_forward(flavour, dev, api):
+    from oracle import msda_oracle
+    from uninext_amd import workloads
+    MSDA, lib = api
+    x = workloads.make_inputs("encoder", flavour, batch=2, seed=3, device=dev)
+    out = MSDA.ms_deform_attn_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], 64)
+    assert out.shape == (2, 22223, 256) and lib.last_kernel("forward") == "msda_fwd_lanegroup"
+    # (1) the oracle on a subset of queries (outputs of different queries are independent)
+    idx = torch.cat([torch.arange(0, 300), torch.arange(16600, 16800), torch.arange(22000, 22223),
+                     torch.randint(0, 22223, (500,), generator=torch.Generator().manual_seed(1))])
+    ref = msda_oracle.forward(x["value"], x["shapes"], x["lsi"], x["loc"][:, idx.to(dev)].contiguous(),
+                              x["attn"][:, idx.to(dev)].contiguous())
+    assert max_abs(_np(out[:, idx.to(dev)]), ref) < 1e-4
+    # (2) linearity in value:  f(2 v + w) = 2 f(v) + f(w)
+    w = torch.randn_like(x["value"])
+    f_w = MSDA.ms_deform_attn_forward(w, x["shapes"], x["lsi"], x["loc"], x["attn"], 64)
+    f_mix = MSDA.ms_deform_attn_forward(2 * x["value"] + w, x["shapes"], x["lsi"], x["loc"], x["attn"], 64)
+    assert float((f_mix - (2 * out + f_w)).abs().max()) < 1e-4
+    # (3) value == 1 everywhere: every output channel of a (query, head) equals the total weight of its valid
+    #     corners, so all 32 channels agree and lie in [0, 1]
+    ones = MSDA.ms_deform_attn_forward(torch.ones_like(x["value"]), x["shapes"], x["lsi"], x["loc"], x["attn"], 64)
+    ones = ones.view(2, 22223, 8, 32)
+    assert float((ones - ones[..., :1]).abs().max()) < 1e-6
+    assert float(ones.min()) >= 0.0 and float(ones.max()) <= 1.0 + 1e-5
+    # (4) determinism: the forward has no atomics -> bitwise repeatable
+    again = MSDA.ms_deform_attn_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], 64)
+    assert torch.equal(out, again)
+
+
+def test_full_size_decoder_forward(dev, api):
+    from oracle import msda_oracle
+    from uninext_amd import workloads
+    MSDA, _ = api
+    x = workloads.make_inputs("decoder", "model", batch=2, seed=4, device=dev)
+    out = MSDA.ms_deform_attn_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], 64)
+    ref = msda_oracle.forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
+    assert max_abs(_np(out), ref) < 1e-4
+
+
+@pytest.mark.parametrize("levels", ["infer", "train"])
+def test_full_size_encoder_backward(levels, dev, api):
+    from oracle import msda_oracle
+    from uninext_amd import workloads
+    MSDA, lib = api
+    lv = workloads.R50_LEVELS_INFER if levels == "infer" else workloads.R50_LEVELS_TRAIN
+    x = workloads.make_inputs("encoder", "model", batch=2, levels=lv, seed=6, device=dev)
+    S = x["value"].shape[1]
+    out = MSDA.ms_deform_attn_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], 64)
+    go = torch.randn(out.shape, generator=torch.Generator().manual_seed(8)).to(dev)
+    gv, gl, ga = MSDA.ms_deform_attn_backward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], go, 64)
+    assert lib.last_kernel("backward") == "msda_bwd_lanegroup"
+    # per-query gradients: oracle on a query subset
+    idx = torch.cat([torch.arange(0, 200), torch.arange(S - 200, S),
+                     torch.randint(0, S, (400,), generator=torch.Generator().manual_seed(2))]).to(dev)
+    _, ogl, oga = msda_oracle.backward(go[:, idx].contiguous(), x["value"], x["shapes"], x["lsi"],
+                                       x["loc"][:, idx].contiguous(), x["attn"][:, idx].contiguous())
+    assert scaled_err(_np(ga[:, idx]), oga) < 1e-4
+    assert scaled_err(_np(gl[:, idx]), ogl) < 1e-3
+    # out is linear in value and in attn:  <grad_value, value> = <grad_out, out> = <grad_attn, attn>
+    dot = float((go.double() * out.double()).sum())
+    scale = float((go.double() * out.double()).abs().sum())
+    assert abs(float((gv.double() * x["value"].double()).sum()) - dot) < 1e-5 * scale
+    assert abs(float((ga.double() * x["attn"].double()).sum()) - dot) < 1e-5 * scale
+    # grad_value of a query subset alone (small enough for the oracle) -- checks the scatter addresses
+    sub = torch.arange(1000, 1400).to(dev)
+    gv_sub, _, _ = MSDA.ms_deform_attn_backward(x["value"], x["shapes"], x["lsi"], x["loc"][:, sub].contiguous(),
+                                                x["attn"][:, sub].contiguous(), go[:, sub].contiguous(), 64)
+    ogv, _, _ = msda_oracle.backward(go[:, sub].contiguous(), x["value"], x["shapes"], x["lsi"],
+                                     x["loc"][:, sub].contiguous(), x["attn"][:, sub].contiguous())
+    assert scaled_err(_np(gv_sub), ogv) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference's own self-test procedure (ops/test.py) on top of the Function
+
+def _testpy_inputs(dev, channels, dtype):
+    N, M, Lq, L, P = 1, 2, 2, 2, 2
+    shapes = torch.as_tensor([(6, 4), (3, 2)], dtype=torch.long, device=dev)
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    S = int(shapes.prod(1).sum())
+    value = (torch.rand(N, S, M, channels, device=dev) * 0.01).to(dtype)
+    loc = torch.rand(N, Lq, M, L, P, 2, device=dev).to(dtype)
+    attn = torch.rand(N, Lq, M, L, P, device=dev) + 1e-5
+    attn = (attn / attn.sum(-1, keepdim=True).sum(-2, keepdim=True)).to(dtype)
+    return value, shapes, lsi, loc, attn
+
+
+def test_reference_selftest_forward(dev, api):
+    """ops/test.py:31-60 with the same tolerances."""
+    from oracle.msda_gridsample import msda_gridsample
+    from uninext_amd.functions import MSDeformAttnFunction
+    torch.manual_seed(3)
+    v, sh, lsi, loc, attn = _testpy_inputs(dev, 2, torch.float64)
+    out = MSDeformAttnFunction.apply(v, sh, lsi, loc, attn, 2)
+    ref = msda_gridsample(v.cpu(), sh.tolist(), loc.cpu(), attn.cpu())
+    assert torch.allclose(out.cpu(), ref)
+    v, sh, lsi, loc, attn = _testpy_inputs(dev, 2, torch.float32)
+    out = MSDeformAttnFunction.apply(v, sh, lsi, loc, attn, 2)
+    ref = msda_gridsample(v.cpu(), sh.tolist(), loc.cpu(), attn.cpu())
+    assert torch.allclose(out.cpu(), ref, rtol=1e-2, atol=1e-3)
+    assert float((out.cpu() - ref).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("channels", [30, 32, 64, 71, 1025, 2048, 3096])
+def test_reference_selftest_gradcheck(channels, dev, api):
+    """ops/test.py:63-78,85: fp64 gradcheck at the channel counts that exercised each CUDA backward variant."""
+    from torch.autograd import gradcheck
+    from uninext_amd.functions import MSDeformAttnFunction
+    torch.manual_seed(3)
+    v, sh, lsi, loc, attn = _testpy_inputs(dev, channels, torch.float64)
+    v.requires_grad_(True)
+    loc.requires_grad_(True)
+    attn.requires_grad_(True)
+    # the full numerical Jacobian at D >= 1025 is ~10^5 forward launches; use torch's fast mode there
+    assert gradcheck(MSDeformAttnFunction.apply, (v, sh, lsi, loc, attn, 2), fast_mode=channels > 100)
+
+
+def test_autocast_casts_to_fp32(dev, api):
+    """custom_fwd(cast_inputs=float32), ops/functions/ms_deform_attn_func.py:23."""
+    from uninext_amd.functions import MSDeformAttnFunction
+    torch.manual_seed(0)
+    v, sh, lsi, loc, attn = _testpy_inputs(dev, 32, torch.float16)
+    with torch.autocast("cuda", dtype=torch.float16):
+        out = MSDeformAttnFunction.apply(v, sh, lsi, loc, attn, 64)
+    assert out.dtype == torch.float32
+
+
+# ------------------------------------------------------------------------------------------------
+# boundary behaviour
+
+def test_errors_and_empty(dev, api):
+    MSDA, lib = api
+    g = load_golden("d32_l4_p4")
+    v, sh, lsi, loc, attn, go = _to(g, dev, torch.float32)
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        MSDA.ms_deform_attn_forward(v.cpu(), sh.cpu(), lsi.cpu(), loc.cpu(), attn.cpu(), 64)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        MSDA.ms_deform_attn_forward(v.transpose(1, 2).contiguous().transpose(1, 2), sh, lsi, loc, attn, 64)
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        MSDA.ms_deform_attn_forward(v, sh.cpu(), lsi, loc, attn, 64)
+    with pytest.raises(RuntimeError, match="must divide"):
+        MSDA.ms_deform_attn_forward(torch.cat([v, v[:1]]), sh, lsi, torch.cat([loc, loc[:1]]),
+                                    torch.cat([attn, attn[:1]]), 2)  # batch 3, im2col_step 2 (cu:50-52)
+    with pytest.raises(RuntimeError, match="dtype"):
+        MSDA.ms_deform_attn_forward(v.half(), sh, lsi, loc.half(), attn.half(), 64)
+    # empty query set / empty batch: no launch, empty result
+    out = MSDA.ms_deform_attn_forward(v, sh, lsi, loc[:, :0].contiguous(), attn[:, :0].contiguous(), 64)
+    assert out.shape == (2, 0, 256)
+    out = MSDA.ms_deform_attn_forward(v[:0], sh, lsi, loc[:0], attn[:0], 64)
+    assert out.shape == (0, 37, 256)
+    gv, gl, ga = MSDA.ms_deform_attn_backward(v, sh, lsi, loc[:, :0].contiguous(), attn[:, :0].contiguous(),
+                                              go[:, :0].contiguous(), 64)
+    assert gv.shape == v.shape and float(gv.abs().sum()) == 0.0 and gl.numel() == 0 and ga.numel() == 0
+
+
+def test_nonfinite_and_huge_locations(dev, api):
+    """NaN / inf / 1e30 sampling locations are 'outside' (the reference's range test is false for them)."""
+    from oracle import msda_oracle
+    MSDA, _ = api
+    g = load_golden("d32_l4_p4")
+    v, sh, lsi, loc, attn, go = _to(g, dev, torch.float32)
+    loc = loc.clone()
+    loc[0, 0, 0, 0, 0, 0] = float("nan")
+    loc[0, 1, 1, 1, 1, 1] = float("inf")
+    loc[1, 2, 2, 2, 2, 0] = -1e30
+    loc[1, 3, 3, 3, 3, 1] = 3e9
+    out = MSDA.ms_deform_attn_forward(v, sh, lsi, loc, attn, 64)
+    ref = msda_oracle.forward(v, sh, lsi, loc, attn)
+    assert torch.isfinite(out).all() and max_abs(_np(out), ref) < 1e-4
+    gv, gl, ga = MSDA.ms_deform_attn_backward(v, sh, lsi, loc, attn, go, 64)
+    ogv, ogl, oga = msda_oracle.backward(go, v, sh, lsi, loc, attn)
+    assert torch.isfinite(gv).all() and torch.isfinite(gl).all() and torch.isfinite(ga).all()
+    assert scaled_err(_np(gv), ogv) < 1e-4 and scaled_err(_np(ga), oga) < 1e-4 and scaled_err(_np(gl), ogl) < 1e-3
+
+
+def test_runs_on_current_stream_and_in_graph(dev, api):
+    """Kernels are enqueued on PyTorch's current stream (ms_deform_attn_cuda.cu:65) and are capturable."""
+    MSDA, _ = api
+    g = load_golden("d32_l4_p4")
+    v, sh, lsi, loc, attn, _ = _to(g, dev, torch.float32)
+    base = MSDA.ms_deform_attn_forward(v, sh, lsi, loc, attn, 64)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        on_side = MSDA.ms_deform_attn_forward(v, sh, lsi, loc, attn, 64)
+    s.synchronize()
+    assert torch.equal(base, on_side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        captured = MSDA.ms_deform_attn_forward(v, sh, lsi, loc, attn, 64)
+    captured.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(base, captured)
+
+
+# ------------------------------------------------------------------------------------------------
+# the module on top (ops/modules/ms_deform_attn.py)
+
+@pytest.mark.parametrize("ref_dim", [2, 4])
+def test_module_forward_backward_vs_gridsample_port(ref_dim, dev, api):
+    import torch.nn.functional as F
+    from oracle.msda_gridsample import msda_gridsample
+    from uninext_amd.modules import MSDeformAttn
+    from uninext_amd.workloads import level_tensors
+    torch.manual_seed(11)
+    levels = ((10, 13), (5, 7), (3, 4), (2, 2))
+    S = sum(h * w for h, w in levels)
+    N, Lq = 2, 31
+    attn = MSDeformAttn(256, 4, 8, 4).to(dev)
+    with torch.no_grad():  # move off the zero-weight init so every projection matters
+        attn.sampling_offsets.weight.normal_(0, 0.02)
+        attn.attention_weights.weight.normal_(0, 0.1)
+    query = torch.randn(N, Lq, 256, device=dev, requires_grad=True)
+    src = torch.randn(N, S, 256, device=dev, requires_grad=True)
+    ref_pts = torch.rand(N, Lq, 4, ref_dim, device=dev)
+    if ref_dim == 4:
+        ref_pts[..., 2:] = ref_pts[..., 2:] * 0.3 + 0.05
+    mask = torch.zeros(N, S, dtype=torch.bool, device=dev)
+    mask[1, -7:] = True
+    sh, lsi = level_tensors(levels, dev)
+    out = attn(query, ref_pts, src, sh, lsi, mask)
+    go = torch.randn_like(out)
+    params = list(attn.parameters())
+    grads = torch.autograd.grad(out, [query, src] + params, go)
+
+    # the same computation with the sampling core swapped for the grid_sample port
+    value = attn.value_proj(src).masked_fill(mask[..., None], 0.0).view(N, S, 8, 32)
+    off = attn.sampling_offsets(query).view(N, Lq, 8, 4, 4, 2)
+    w = F.softmax(attn.attention_weights(query).view(N, Lq, 8, 16), -1).view(N, Lq, 8, 4, 4)
+    if ref_dim == 2:
+        wh = torch.stack([sh[..., 1], sh[..., 0]], -1)
+        loc = ref_pts[:, :, None, :, None, :] + off / wh[None, None, None, :, None, :]
+    else:
+        loc = ref_pts[:, :, None, :, None, :2] + off / 4 * ref_pts[:, :, None, :, None, 2:] * 0.5
+    ref_out = attn.output_proj(msda_gridsample(value, levels, loc, w))
+    ref_grads = torch.autograd.grad(ref_out, [query, src] + params, go)
+    assert float((out - ref_out).abs().max()) < 1e-4
+    for a, b in zip(grads, ref_grads):
+        assert float((a - b).abs().max()) < 2e-4 * max(1.0, float(b.abs().max()))

@@ -1,0 +1,72 @@
+#!/usr/bin/env python
+"""Kernel-level A/B timing of the MSDeformAttn variants at the R50 shapes (GPU box only).
+
+    python tools/kbench.py [--reps 30] [--variants-fwd 1,2] [--variants-bwd 1,2] [--kinds encoder,decoder]
+
+Prints one line per (direction, kind, flavour, variant): mean launch time over `reps` back-to-back launches
+(HIP events on the launch stream), algorithmic GB/s and the fraction of the 8 TB/s HBM roofline.
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from uninext_amd import _lib, ext, workloads  # noqa: E402
+
+
+def timeit(fn, reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e3  # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--variants-fwd", default="")
+    ap.add_argument("--variants-bwd", default="")
+    ap.add_argument("--kinds", default="encoder,decoder")
+    ap.add_argument("--flavours", default="model,uniform")
+    ap.add_argument("--batch", type=int, default=2)
+    ap.add_argument("--no-bwd", action="store_true")
+    args = ap.parse_args()
+    _lib.load()
+    vf = [int(v) for v in args.variants_fwd.split(",") if v] or list(range(1, len(_lib.variants("forward"))))
+    vb = [int(v) for v in args.variants_bwd.split(",") if v] or list(range(1, len(_lib.variants("backward"))))
+    for kind in args.kinds.split(","):
+        for flavour in args.flavours.split(","):
+            x = workloads.make_inputs(kind, flavour, batch=args.batch, seed=1)
+            N, S = x["value"].shape[:2]
+            Lq = x["loc"].shape[1]
+            a = (x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
+            fb = workloads.algorithmic_bytes_forward(N, S, Lq)
+            for v in vf:
+                _lib.set_variant("forward", v)
+                us = timeit(lambda: ext.ms_deform_attn_forward(*a, 64), args.reps)
+                print("fwd %-8s %-8s %-22s %9.1f us  %8.1f GB/s  %5.1f%% of 8TB/s" % (
+                    kind, flavour, _lib.last_kernel("forward") + "#%d" % v, us, fb / us / 1e3, fb / us / 1e3 / 80), flush=True)
+            _lib.set_variant("forward", 0)
+            if args.no_bwd:
+                continue
+            go = torch.randn(N, Lq, x["value"].shape[2] * x["value"].shape[3], device="cuda")
+            bb = workloads.algorithmic_bytes_backward(N, S, Lq)
+            for v in vb:
+                _lib.set_variant("backward", v)
+                us = timeit(lambda: ext.ms_deform_attn_backward(*a, go, 64), max(3, args.reps // 3))
+                print("bwd %-8s %-8s %-22s %9.1f us  %8.1f GB/s  %5.1f%% of 8TB/s (incl. grad_value memset)" % (
+                    kind, flavour, _lib.last_kernel("backward") + "#%d" % v, us, bb / us / 1e3, bb / us / 1e3 / 80), flush=True)
+            _lib.set_variant("backward", 0)
+
+
+if __name__ == "__main__":
+    main()

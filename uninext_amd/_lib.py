@@ -1,0 +1,74 @@
+"""ctypes binding of include/msda_hip.h.  Loading never falls back to anything: if the HIP
+library is absent the import of the op fails loudly (there is no CPU or eager path)."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmsda_hip.so")
+
+ABI_VERSION = 1
+EXPORTS = (
+    "msda_hip_abi_version", "msda_hip_last_error",
+    "msda_hip_forward_f32", "msda_hip_forward_f64", "msda_hip_backward_f32", "msda_hip_backward_f64",
+    "msda_hip_set_variant", "msda_hip_get_variant", "msda_hip_variant_name", "msda_hip_last_kernel",
+)
+
+_lib = None
+
+
+def load():
+    """Return the loaded library (cached).  Raises RuntimeError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "MultiScaleDeformableAttention: %s not found. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C uninext_amd/csrc` "
+            "(hipcc, gfx950). There is no fallback implementation." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    i, p, s = ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
+    lib.msda_hip_abi_version.argtypes, lib.msda_hip_abi_version.restype = [], i
+    lib.msda_hip_last_error.argtypes, lib.msda_hip_last_error.restype = [], s
+    for suf in ("f32", "f64"):
+        f = getattr(lib, "msda_hip_forward_" + suf)
+        f.argtypes, f.restype = [p, p, p, p, p, i, i, i, i, i, i, i, p, p], i
+        g = getattr(lib, "msda_hip_backward_" + suf)
+        g.argtypes, g.restype = [p, p, p, p, p, p, i, i, i, i, i, i, i, p, p, p, p], i
+    lib.msda_hip_set_variant.argtypes, lib.msda_hip_set_variant.restype = [i, i], i
+    lib.msda_hip_get_variant.argtypes, lib.msda_hip_get_variant.restype = [i], i
+    lib.msda_hip_variant_name.argtypes, lib.msda_hip_variant_name.restype = [i, i], s
+    lib.msda_hip_last_kernel.argtypes, lib.msda_hip_last_kernel.restype = [i], s
+    got = lib.msda_hip_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError("libmsda_hip.so ABI version %d, binding expects %d: rebuild" % (got, ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().msda_hip_last_error().decode()
+
+
+def set_variant(which, variant):
+    """which: 'forward' | 'backward'; variant: int or name (see variants())."""
+    w = {"forward": 0, "backward": 1}[which]
+    if isinstance(variant, str):
+        variant = variants(which).index(variant)
+    if load().msda_hip_set_variant(w, int(variant)) != 0:
+        raise ValueError(last_error())
+
+
+def variants(which):
+    w = {"forward": 0, "backward": 1}[which]
+    out, k = [], 0
+    while True:
+        n = load().msda_hip_variant_name(w, k)
+        if n is None:
+            return out
+        out.append(n.decode())
+        k += 1
+
+
+def last_kernel(which):
+    return load().msda_hip_last_kernel({"forward": 0, "backward": 1}[which]).decode()

@@ -1,0 +1,138 @@
+// extern "C" surface of libmsda_hip.so -- see include/msda_hip.h for the contract.
+// Mirrors the argument checks of the reference host launcher
+// (ops/src/cuda/ms_deform_attn_cuda.cu:28-52) that are expressible on raw pointers.
+#include "../../include/msda_hip.h"
+
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "msda_common.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+thread_local const char* g_last_kernel[2] = {"", ""};
+std::atomic<int> g_variant[2] = {{-1}, {-1}};  // -1: not initialised (read env once)
+
+const char* const kVariantNames[2][msda::kNumVariants] = {
+    {"auto", "msda_fwd_generic", "msda_fwd_lanegroup"},
+    {"auto", "msda_bwd_generic", "msda_bwd_lanegroup"},
+};
+
+int current_variant(int which) {
+  int v = g_variant[which].load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = std::getenv(which == 0 ? "MSDA_HIP_FWD_VARIANT" : "MSDA_HIP_BWD_VARIANT");
+    v = e ? std::atoi(e) : 0;
+    if (v < 0 || v >= msda::kNumVariants) v = 0;
+    g_variant[which].store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
+
+int fail(int code, const char* what) {
+  std::snprintf(g_err, sizeof(g_err), "%s", what);
+  return code;
+}
+
+int check_dims(const msda::Dims& d) {
+  if (d.N < 0 || d.Lq < 0) return fail(MSDA_ERR_BAD_DIMS, "batch and num_query must be >= 0");
+  if (d.S <= 0 || d.M <= 0 || d.D <= 0 || d.L <= 0 || d.P <= 0)
+    return fail(MSDA_ERR_BAD_DIMS, "spatial_size, num_heads, channels, num_levels, num_point must be > 0");
+  if ((int64_t)d.Lq * d.M * d.L * d.P * 2 >= (int64_t)1 << 40 || (int64_t)d.S * d.M * d.D >= (int64_t)1 << 40)
+    return fail(MSDA_ERR_TOO_LARGE, "per-image extent too large");
+  return 0;
+}
+
+int finish(int rc, const char* what) {
+  if (rc == 0) return 0;
+  std::snprintf(g_err, sizeof(g_err), "%s: launch failed: %s (hipError_t %d)", what,
+                hipGetErrorString((hipError_t)rc), rc);
+  return rc;
+}
+
+template <typename T>
+int forward_impl(const T* value, const int64_t* shapes, const int64_t* lsi, const T* loc, const T* attn,
+                 const msda::Dims& d, T* out, void* stream) {
+  if (int rc = check_dims(d)) return rc;
+  if (d.N == 0 || d.Lq == 0) return 0;
+  if (!value || !shapes || !lsi || !loc || !attn || !out) return fail(MSDA_ERR_NULL_POINTER, "null pointer argument");
+  const int rc = msda::launch_forward<T>(current_variant(0), value, shapes, lsi, loc, attn, d, out,
+                                         (hipStream_t)stream, &g_last_kernel[0]);
+  return finish(rc, "msda_hip_forward");
+}
+
+template <typename T>
+int backward_impl(const T* grad_out, const T* value, const int64_t* shapes, const int64_t* lsi, const T* loc,
+                  const T* attn, const msda::Dims& d, T* grad_value, T* grad_loc, T* grad_attn, void* stream) {
+  if (int rc = check_dims(d)) return rc;
+  if (d.N == 0 || d.Lq == 0) return 0;
+  if (!grad_out || !value || !shapes || !lsi || !loc || !attn || !grad_value || !grad_loc || !grad_attn)
+    return fail(MSDA_ERR_NULL_POINTER, "null pointer argument");
+  const int rc = msda::launch_backward<T>(current_variant(1), grad_out, value, shapes, lsi, loc, attn, d, grad_value,
+                                          grad_loc, grad_attn, (hipStream_t)stream, &g_last_kernel[1]);
+  return finish(rc, "msda_hip_backward");
+}
+
+}  // namespace
+
+extern "C" {
+
+int msda_hip_abi_version(void) { return MSDA_HIP_ABI_VERSION; }
+const char* msda_hip_last_error(void) { return g_err; }
+
+int msda_hip_forward_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                         const float* sampling_loc, const float* attn_weight, int batch, int spatial_size,
+                         int num_heads, int channels, int num_levels, int num_query, int num_point, float* output,
+                         void* stream) {
+  const msda::Dims d{batch, spatial_size, num_heads, channels, num_levels, num_query, num_point};
+  return forward_impl<float>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, d, output, stream);
+}
+
+int msda_hip_forward_f64(const double* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                         const double* sampling_loc, const double* attn_weight, int batch, int spatial_size,
+                         int num_heads, int channels, int num_levels, int num_query, int num_point, double* output,
+                         void* stream) {
+  const msda::Dims d{batch, spatial_size, num_heads, channels, num_levels, num_query, num_point};
+  return forward_impl<double>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, d, output, stream);
+}
+
+int msda_hip_backward_f32(const float* grad_output, const float* value, const int64_t* spatial_shapes,
+                          const int64_t* level_start_index, const float* sampling_loc, const float* attn_weight,
+                          int batch, int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                          int num_point, float* grad_value, float* grad_sampling_loc, float* grad_attn_weight,
+                          void* stream) {
+  const msda::Dims d{batch, spatial_size, num_heads, channels, num_levels, num_query, num_point};
+  return backward_impl<float>(grad_output, value, spatial_shapes, level_start_index, sampling_loc, attn_weight, d,
+                              grad_value, grad_sampling_loc, grad_attn_weight, stream);
+}
+
+int msda_hip_backward_f64(const double* grad_output, const double* value, const int64_t* spatial_shapes,
+                          const int64_t* level_start_index, const double* sampling_loc, const double* attn_weight,
+                          int batch, int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                          int num_point, double* grad_value, double* grad_sampling_loc, double* grad_attn_weight,
+                          void* stream) {
+  const msda::Dims d{batch, spatial_size, num_heads, channels, num_levels, num_query, num_point};
+  return backward_impl<double>(grad_output, value, spatial_shapes, level_start_index, sampling_loc, attn_weight, d,
+                               grad_value, grad_sampling_loc, grad_attn_weight, stream);
+}
+
+int msda_hip_set_variant(int which, int variant) {
+  if (which < 0 || which > 1 || variant < 0 || variant >= msda::kNumVariants)
+    return fail(MSDA_ERR_BAD_VARIANT, "unknown kernel variant");
+  g_variant[which].store(variant, std::memory_order_relaxed);
+  return 0;
+}
+
+int msda_hip_get_variant(int which) { return (which < 0 || which > 1) ? MSDA_ERR_BAD_VARIANT : current_variant(which); }
+
+const char* msda_hip_variant_name(int which, int variant) {
+  if (which < 0 || which > 1 || variant < 0 || variant >= msda::kNumVariants) return nullptr;
+  return kVariantNames[which][variant];
+}
+
+const char* msda_hip_last_kernel(int which) { return (which < 0 || which > 1) ? "" : g_last_kernel[which]; }
+
+}  // extern "C"

@@ -1,0 +1,85 @@
+// Shared device/host helpers for the gfx950 MSDeformAttn kernels (internal, not part of the C ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace msda {
+
+constexpr int kBlock = 256;      // 4 wave64 per workgroup
+constexpr int kMaxLP = 128;      // lane-group kernels keep a per-sample (H, W, start) table in LDS
+constexpr int kLevelTableBytes = 3 * kMaxLP * 4;  // multiple of 16: the records behind it stay aligned
+constexpr uint32_t kOobOffset = 0x80000000u;  // buffer offset that is always past num_records (< 2 GiB)
+
+// GCC-style vector: the type __builtin_amdgcn_raw_buffer_load_b128 returns (an ext_vector_type
+// typedef silently converts through a scalar splat on this compiler).
+typedef unsigned int u32x4 __attribute__((__vector_size__(16)));
+typedef float f32x4 __attribute__((__vector_size__(16)));
+
+// 16-byte raw buffer load as 4 floats.  NB: never __builtin_bit_cast a single vector ELEMENT
+// (`bit_cast(float, v[i])` reads element 0 for every i on this compiler); cast the whole vector.
+__device__ __forceinline__ f32x4 buffer_load_f32x4(__amdgpu_buffer_rsrc_t rsrc, uint32_t voffset, uint32_t soffset) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, 0));
+}
+
+struct Dims {
+  int N, S, M, D, L, Lq, P;
+};
+
+// One bilinear sample of level (H, W): the reference's per-sample arithmetic
+// (ops/src/cuda/ms_deform_im2col_cuda.cuh:282-288 and :38-46).
+template <typename T>
+struct Sample {
+  T lh, lw, hh, hw;          // fractional parts and their complements
+  int h_low, w_low;          // top-left corner (may be -1)
+  bool in_range;             // the reference's `h_im > -1 && w_im > -1 && h_im < H && w_im < W`
+  bool ok1, ok2, ok3, ok4;   // per-corner validity (top-left, top-right, bottom-left, bottom-right)
+};
+
+template <typename T>
+__device__ __forceinline__ Sample<T> make_sample(T loc_w, T loc_h, int H, int W) {
+  Sample<T> s;
+  const T h_im = loc_h * (T)H - (T)0.5;
+  const T w_im = loc_w * (T)W - (T)0.5;
+  s.in_range = (h_im > (T)-1) && (w_im > (T)-1) && (h_im < (T)H) && (w_im < (T)W);
+  const T hf = floor(h_im), wf = floor(w_im);
+  // Out-of-range samples may carry huge / NaN coordinates: keep the int conversion defined.
+  s.h_low = s.in_range ? (int)hf : 0;
+  s.w_low = s.in_range ? (int)wf : 0;
+  s.lh = h_im - hf;
+  s.lw = w_im - wf;
+  s.hh = (T)1 - s.lh;
+  s.hw = (T)1 - s.lw;
+  const bool t = s.in_range && s.h_low >= 0, bt = s.in_range && s.h_low + 1 <= H - 1;
+  const bool lf = s.w_low >= 0, rt = s.w_low + 1 <= W - 1;
+  s.ok1 = t && lf;
+  s.ok2 = t && rt;
+  s.ok3 = bt && lf;
+  s.ok4 = bt && rt;
+  return s;
+}
+
+__device__ __forceinline__ void atomic_add(float* p, float v) { unsafeAtomicAdd(p, v); }
+__device__ __forceinline__ void atomic_add(double* p, double v) { unsafeAtomicAdd(p, v); }
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Launchers implemented in msda_fwd.hip / msda_bwd.hip.  `kernel_name` receives a static string.
+template <typename T>
+int launch_forward(int variant, const T* value, const int64_t* shapes, const int64_t* lsi, const T* loc,
+                   const T* attn, const Dims& d, T* out, hipStream_t stream, const char** kernel_name);
+
+template <typename T>
+int launch_backward(int variant, const T* grad_out, const T* value, const int64_t* shapes, const int64_t* lsi,
+                    const T* loc, const T* attn, const Dims& d, T* grad_value, T* grad_loc, T* grad_attn,
+                    hipStream_t stream, const char** kernel_name);
+
+// Variant numbering shared with include/msda_hip.h.
+enum Variant { kAuto = 0, kGeneric = 1, kLaneGroup = 2, kNumVariants = 3 };
+
+}  // namespace msda

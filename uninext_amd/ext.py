@@ -1,0 +1,94 @@
+"""The two functions of the reference's pybind module `MultiScaleDeformableAttention`
+(ops/src/vision.cpp:13-16), same names / argument order / error behaviour, implemented by
+calling the C ABI of libmsda_hip.so with raw device pointers and PyTorch's current stream.
+
+Reference host code mirrored: ops/src/ms_deform_attn.h:21-61 (device dispatch: CPU tensors
+raise "Not implemented on the CPU") and ops/src/cuda/ms_deform_attn_cuda.cu:28-52
+(contiguity / device / im2col_step checks), :54 and :121-123 (output allocation).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+_SUFFIX = {torch.float32: "f32", torch.float64: "f64"}
+
+
+def _check(name, t, dev):
+    if not t.is_contiguous():
+        raise RuntimeError("%s tensor has to be contiguous" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s must be a CUDA tensor" % name)  # "CUDA" == the HIP device on PyTorch-ROCm
+    if t.device != dev:
+        raise RuntimeError("%s is on %s but value is on %s" % (name, t.device, dev))
+
+
+def _dims(value, spatial_shapes, sampling_loc, im2col_step):
+    if value.dim() != 4 or sampling_loc.dim() != 6 or spatial_shapes.dim() != 2:
+        raise RuntimeError("expected value [N,S,M,D], spatial_shapes [L,2], sampling_loc [N,Lq,M,L,P,2]")
+    batch, spatial_size, num_heads, channels = value.shape
+    num_levels = spatial_shapes.shape[0]
+    num_query, num_point = sampling_loc.shape[1], sampling_loc.shape[4]
+    step = min(batch, int(im2col_step))
+    if batch > 0 and (step <= 0 or batch % step != 0):
+        raise RuntimeError("batch(%d) must divide im2col_step(%d)" % (batch, step))
+    return batch, spatial_size, num_heads, channels, num_levels, num_query, num_point
+
+
+def _prep(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, extra=()):
+    if not value.is_cuda:
+        raise RuntimeError("Not implemented on the CPU")  # ops/src/ms_deform_attn.h:38
+    if value.dtype not in _SUFFIX:
+        raise RuntimeError("ms_deform_attn: unsupported dtype %s (float32/float64 only)" % value.dtype)
+    dev = value.device
+    _check("value", value, dev)
+    _check("spatial_shapes", spatial_shapes, dev)
+    _check("level_start_index", level_start_index, dev)
+    _check("sampling_loc", sampling_loc, dev)
+    _check("attn_weight", attn_weight, dev)
+    for name, t in extra:
+        _check(name, t, dev)
+    for name, t in (("sampling_loc", sampling_loc), ("attn_weight", attn_weight)) + tuple(extra):
+        if t.dtype != value.dtype:
+            raise RuntimeError("%s has dtype %s, value has %s" % (name, t.dtype, value.dtype))
+    if spatial_shapes.dtype != torch.int64 or level_start_index.dtype != torch.int64:
+        raise RuntimeError("spatial_shapes and level_start_index must be int64")
+    return _lib.load(), _SUFFIX[value.dtype]
+
+
+def _raise(rc):
+    raise RuntimeError("MultiScaleDeformableAttention (HIP): %s [code %d]" % (_lib.last_error(), rc))
+
+
+def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
+    lib, suf = _prep(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+    N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, sampling_loc, im2col_step)
+    out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)  # kernel writes every element
+    with torch.cuda.device(value.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = getattr(lib, "msda_hip_forward_" + suf)(
+            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
+            attn_weight.data_ptr(), N, S, M, D, L, Lq, P, out.data_ptr(), ctypes.c_void_p(stream))
+    if rc != 0:
+        _raise(rc)
+    return out
+
+
+def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output,
+                            im2col_step):
+    lib, suf = _prep(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                     extra=(("grad_output", grad_output),))
+    N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, sampling_loc, im2col_step)
+    grad_value = torch.zeros_like(value)               # accumulated with atomics
+    grad_loc = torch.empty_like(sampling_loc)          # every element written by the kernel
+    grad_attn = torch.empty_like(attn_weight)
+    with torch.cuda.device(value.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = getattr(lib, "msda_hip_backward_" + suf)(
+            grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+            sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P, grad_value.data_ptr(),
+            grad_loc.data_ptr(), grad_attn.data_ptr(), ctypes.c_void_p(stream))
+    if rc != 0:
+        _raise(rc)
+    return [grad_value, grad_loc, grad_attn]

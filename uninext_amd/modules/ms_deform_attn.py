@@ -1,0 +1,89 @@
+"""`MSDeformAttn` -- the multi-scale deformable attention layer that owns the operator.
+
+Host-side mirror of the reference's ops/modules/ms_deform_attn.py:30-116: same constructor
+arguments, parameter names (`sampling_offsets`, `attention_weights`, `value_proj`,
+`output_proj` -- reference checkpoints load unchanged), initialisation (:54-76), argument
+meaning and errors of `forward` (:79-116).  The four projections stay PyTorch-ROCm GEMMs
+(rocBLAS/hipBLASLt); the sampling itself is `MSDeformAttnFunction` -> libmsda_hip.so.
+"""
+import math
+import warnings
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.nn.init import constant_, xavier_uniform_
+
+from ..functions import MSDeformAttnFunction
+
+
+def _is_power_of_2(n):
+    if not isinstance(n, int) or n < 0:
+        raise ValueError("invalid input for _is_power_of_2: {} (type: {})".format(n, type(n)))
+    return n != 0 and (n & (n - 1)) == 0
+
+
+class MSDeformAttn(nn.Module):
+    def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4):
+        super().__init__()
+        if d_model % n_heads != 0:
+            raise ValueError("d_model must be divisible by n_heads, but got {} and {}".format(d_model, n_heads))
+        if not _is_power_of_2(d_model // n_heads):
+            warnings.warn("MSDeformAttn: a per-head dimension that is a power of 2 (and a multiple of 4) takes the "
+                          "lane-group HIP kernels; other sizes fall back to the generic kernels.")
+        self.im2col_step = 64  # kept for interface parity (ops/modules/ms_deform_attn.py:48); no effect on the HIP path
+        self.d_model, self.n_levels, self.n_heads, self.n_points = d_model, n_levels, n_heads, n_points
+
+        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
+        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
+        self.value_proj = nn.Linear(d_model, d_model)
+        self.output_proj = nn.Linear(d_model, d_model)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        # ops/modules/ms_deform_attn.py:61-76: zero offset weights, a ring of unit directions (one per head)
+        # scaled by the point index as the offset bias, uniform attention, xavier projections.
+        constant_(self.sampling_offsets.weight.data, 0.0)
+        angle = torch.arange(self.n_heads, dtype=torch.float32) * (2.0 * math.pi / self.n_heads)
+        ring = torch.stack([angle.cos(), angle.sin()], -1)
+        ring = ring / ring.abs().max(-1, keepdim=True)[0]
+        ring = ring.view(self.n_heads, 1, 1, 2).repeat(1, self.n_levels, self.n_points, 1)
+        ring = ring * torch.arange(1, self.n_points + 1, dtype=torch.float32).view(1, 1, self.n_points, 1)
+        with torch.no_grad():
+            self.sampling_offsets.bias = nn.Parameter(ring.reshape(-1))
+        constant_(self.attention_weights.weight.data, 0.0)
+        constant_(self.attention_weights.bias.data, 0.0)
+        xavier_uniform_(self.value_proj.weight.data)
+        constant_(self.value_proj.bias.data, 0.0)
+        xavier_uniform_(self.output_proj.weight.data)
+        constant_(self.output_proj.bias.data, 0.0)
+
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
+                input_padding_mask=None):
+        """query (N, Lq, C); reference_points (N, Lq, n_levels, 2|4) in [0,1]; input_flatten (N, sum HW, C);
+        input_spatial_shapes (n_levels, 2) int64 (H, W); input_level_start_index (n_levels,) int64;
+        input_padding_mask (N, sum HW) bool, True = padding.  Returns (N, Lq, C)."""
+        N, Len_q, _ = query.shape
+        N, Len_in, _ = input_flatten.shape
+        assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == Len_in
+
+        value = self.value_proj(input_flatten)
+        if input_padding_mask is not None:
+            value = value.masked_fill(input_padding_mask[..., None], float(0))
+        value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
+        offsets = self.sampling_offsets(query).view(N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
+        weights = self.attention_weights(query).view(N, Len_q, self.n_heads, self.n_levels * self.n_points)
+        weights = F.softmax(weights, -1).view(N, Len_q, self.n_heads, self.n_levels, self.n_points)
+        if reference_points.shape[-1] == 2:
+            wh = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)
+            locations = reference_points[:, :, None, :, None, :] + offsets / wh[None, None, None, :, None, :]
+        elif reference_points.shape[-1] == 4:
+            locations = reference_points[:, :, None, :, None, :2] \
+                + offsets / self.n_points * reference_points[:, :, None, :, None, 2:] * 0.5
+        else:
+            raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(
+                reference_points.shape[-1]))
+        output = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index, locations,
+                                            weights, self.im2col_step)
+        return self.output_proj(output)
