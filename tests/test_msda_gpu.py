@@ -66,12 +66,10 @@ def test_golden_forward_f32(name, variant, dev, api):
         out = MSDA.ms_deform_attn_forward(v, sh, lsi, loc, attn, 64)
     finally:
         lib.set_variant("forward", "auto")
-    D = v.shape[3]
-    lanegroup_capable = D % 4 == 0 and (D // 4) & (D // 4 - 1) == 0
-    if variant != "msda_fwd_generic" and lanegroup_capable:
-        assert lib.last_kernel("forward") == "msda_fwd_lanegroup"
-    else:
+    if variant == "msda_fwd_generic" or v.shape[3] % 4 != 0:
         assert lib.last_kernel("forward") == "msda_fwd_generic"
+    elif v.shape[3] == 32:  # the UNINEXT head size must take the lane-group kernel
+        assert lib.last_kernel("forward") == "msda_fwd_lanegroup"
     assert max_abs(_np(out), g["out"]) < 1e-4
 
 
@@ -167,6 +165,59 @@ def test_lanegroup_shapes_vs_oracle(D, M, L, P, dev, api):
     assert scaled_err(_np(gv), ogv) < 1e-4 and scaled_err(_np(ga), oga) < 1e-4 and scaled_err(_np(gl), ogl) < 1e-3
 
 
+TILED_PYRAMIDS = [
+    ((25, 42), (13, 21), (7, 11), (4, 6)),      # R50 pyramid / 4
+    ((8, 8),),                                  # a single tile
+    ((9, 7), (5, 4)),
+    ((16, 16), (16, 16)),                       # two levels of equal resolution
+    ((3, 50), (2, 25), (1, 13)),                # thin images
+    ((10, 10), (20, 20)),                       # a finer level after the first one
+    ((40, 40), (80, 80), (3, 3)),               # windows exceed the LDS budget: a level is served from L2
+    ((17, 23), (9, 12), (5, 6), (3, 3)),
+]
+
+
+@pytest.mark.parametrize("flavour", ["model", "uniform", "wide"])
+@pytest.mark.parametrize("levels", TILED_PYRAMIDS)
+def test_tiled_forward_vs_oracle(levels, flavour, dev, api):
+    """The LDS-tiled encoder kernel (Lq == S) on odd pyramids; far / window-missing samples take its
+    global-memory path, so 'uniform' and 'wide' stress that path and 'model' the LDS path."""
+    from oracle import msda_oracle
+    from uninext_amd import workloads
+    MSDA, lib = api
+    P = 4 if len(levels) <= 4 else 2
+    kw = dict(offset_sigma=6.0) if flavour == "wide" else {}
+    x = workloads.make_inputs("encoder", "model" if flavour == "wide" else flavour, batch=2, levels=levels,
+                              points=P, seed=33, device=dev, **kw)
+    lib.set_variant("forward", "msda_fwd_tiled")
+    try:
+        out = MSDA.ms_deform_attn_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], 64)
+    finally:
+        lib.set_variant("forward", "auto")
+    assert lib.last_kernel("forward") == "msda_fwd_tiled"
+    ref = msda_oracle.forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
+    assert max_abs(_np(out), ref) < 1e-4
+
+
+@pytest.mark.parametrize("M,L,P", [(1, 1, 4), (3, 2, 2), (8, 4, 2), (5, 1, 16), (2, 3, 5)])
+def test_tiled_forward_head_point_counts(M, L, P, dev, api):
+    from oracle import msda_oracle
+    from uninext_amd import workloads
+    MSDA, lib = api
+    levels = ((21, 18), (11, 9), (6, 5), (3, 3))[:L]
+    x = workloads.make_inputs("encoder", "model", batch=1, levels=levels, heads=M, points=P, seed=9, device=dev)
+    x["loc"][0, 3, 0, 0, 0, 0] = float("nan")
+    x["loc"][0, 5, M - 1, L - 1, P - 1, 1] = float("inf")
+    lib.set_variant("forward", "msda_fwd_tiled")
+    try:
+        out = MSDA.ms_deform_attn_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], 64)
+    finally:
+        lib.set_variant("forward", "auto")
+    assert lib.last_kernel("forward") == ("msda_fwd_tiled" if L * P <= 16 else "msda_fwd_lanegroup")
+    ref = msda_oracle.forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
+    assert torch.isfinite(out).all() and max_abs(_np(out), ref) < 1e-4
+
+
 # ------------------------------------------------------------------------------------------------
 # full BASELINE sizes: oracle on a query subset + size-independent properties
 
@@ -177,7 +228,14 @@ def test_full_size_encoder_forward(flavour, dev, api):
     MSDA, lib = api
     x = workloads.make_inputs("encoder", flavour, batch=2, seed=3, device=dev)
     out = MSDA.ms_deform_attn_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], 64)
-    assert out.shape == (2, 22223, 256) and lib.last_kernel("forward") == "msda_fwd_lanegroup"
+    assert out.shape == (2, 22223, 256) and lib.last_kernel("forward") == "msda_fwd_tiled"  # auto for Lq == S
+    lib.set_variant("forward", "msda_fwd_lanegroup")
+    try:
+        out_lg = MSDA.ms_deform_attn_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], 64)
+    finally:
+        lib.set_variant("forward", "auto")
+    assert lib.last_kernel("forward") == "msda_fwd_lanegroup"
+    assert float((out - out_lg).abs().max()) < 2e-5  # two HIP kernels, different summation order only
     # (1) the oracle on a subset of queries (outputs of different queries are independent)
     idx = torch.cat([torch.arange(0, 300), torch.arange(16600, 16800), torch.arange(22000, 22223),
                      torch.randint(0, 22223, (500,), generator=torch.Generator().manual_seed(1))])
@@ -285,7 +343,8 @@ def test_reference_selftest_gradcheck(channels, dev, api):
     loc.requires_grad_(True)
     attn.requires_grad_(True)
     # the full numerical Jacobian at D >= 1025 is ~10^5 forward launches; use torch's fast mode there
-    assert gradcheck(MSDeformAttnFunction.apply, (v, sh, lsi, loc, attn, 2), fast_mode=channels > 100)
+    assert gradcheck(MSDeformAttnFunction.apply, (v, sh, lsi, loc, attn, 2), fast_mode=channels > 100,
+                     nondet_tol=1e-12)  # fp64 atomics: summation order varies run to run (as in the reference)
 
 
 def test_autocast_casts_to_fp32(dev, api):

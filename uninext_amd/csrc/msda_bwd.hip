@@ -139,7 +139,9 @@ msda_bwd_lanegroup(const float* __restrict__ grad_out, const float* __restrict__
     o[1] = sm.ok2 ? o1 + pix_bytes : kOobOffset;
     o[2] = sm.ok3 ? o1 + (uint32_t)W * pix_bytes : kOobOffset;
     o[3] = sm.ok4 ? o1 + (uint32_t)(W + 1) * pix_bytes : kOobOffset;
-    *reinterpret_cast<float4*>(rec + s * 32) = make_float4(sm.lw, sm.lh, a, 0.f);
+    // out-of-range samples (incl. NaN/inf locations) contribute exact zeros, as the reference's skip does
+    *reinterpret_cast<float4*>(rec + s * 32) =
+        sm.in_range ? make_float4(sm.lw, sm.lh, a, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
     *reinterpret_cast<u32x4*>(rec + s * 32 + 16) = o;
   };
 

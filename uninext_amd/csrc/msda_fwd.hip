@@ -194,8 +194,14 @@ int launch_forward<float>(int variant, const float* value, const int64_t* shapes
                           const char** kernel_name) {
   int G = 0;
   const bool lg = lanegroup_ok(d, &G);
-  if (variant == kAuto) variant = lg ? kLaneGroup : kGeneric;
+  const bool tl = tiled_forward_ok(d);
+  if (variant == kAuto) variant = (tl && d.S >= 4096) ? kTiled : (lg ? kLaneGroup : kGeneric);
+  if (variant == kTiled && !tl) variant = lg ? kLaneGroup : kGeneric;
   if (variant == kLaneGroup && !lg) variant = kGeneric;
+  if (variant == kTiled) {
+    *kernel_name = "msda_fwd_tiled";
+    return launch_forward_tiled(value, shapes, lsi, loc, attn, d, out, stream);
+  }
   if (variant == kLaneGroup) {
     const int LP = d.L * d.P;
     *kernel_name = "msda_fwd_lanegroup";
