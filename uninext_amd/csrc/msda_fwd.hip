@@ -21,6 +21,8 @@
 
 namespace msda {
 
+constexpr bool kTiledIsDefault = false;
+
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
@@ -195,7 +197,8 @@ int launch_forward<float>(int variant, const float* value, const int64_t* shapes
   int G = 0;
   const bool lg = lanegroup_ok(d, &G);
   const bool tl = tiled_forward_ok(d);
-  if (variant == kAuto) variant = (tl && d.S >= 4096) ? kTiled : (lg ? kLaneGroup : kGeneric);
+  // the tiled kernel is selected automatically only once it beats the lane-group kernel (kbench A/B)
+  if (variant == kAuto) variant = (kTiledIsDefault && tl && d.S >= 4096) ? kTiled : (lg ? kLaneGroup : kGeneric);
   if (variant == kTiled && !tl) variant = lg ? kLaneGroup : kGeneric;
   if (variant == kLaneGroup && !lg) variant = kGeneric;
   if (variant == kTiled) {
