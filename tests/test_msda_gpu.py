@@ -177,19 +177,22 @@ TILED_PYRAMIDS = [
 ]
 
 
+TILED_VARIANTS = ["msda_fwd_tiled", "msda_fwd_tiled_l0", "msda_fwd_tiled_l0big"]
+
+
+@pytest.mark.parametrize("variant", TILED_VARIANTS)
 @pytest.mark.parametrize("flavour", ["model", "uniform", "wide"])
 @pytest.mark.parametrize("levels", TILED_PYRAMIDS)
-def test_tiled_forward_vs_oracle(levels, flavour, dev, api):
+def test_tiled_forward_vs_oracle(levels, flavour, variant, dev, api):
     """The LDS-tiled encoder kernel (Lq == S) on odd pyramids; far / window-missing samples take its
     global-memory path, so 'uniform' and 'wide' stress that path and 'model' the LDS path."""
     from oracle import msda_oracle
     from uninext_amd import workloads
     MSDA, lib = api
-    P = 4 if len(levels) <= 4 else 2
     kw = dict(offset_sigma=6.0) if flavour == "wide" else {}
     x = workloads.make_inputs("encoder", "model" if flavour == "wide" else flavour, batch=2, levels=levels,
-                              points=P, seed=33, device=dev, **kw)
-    lib.set_variant("forward", "msda_fwd_tiled")
+                              seed=33, device=dev, **kw)
+    lib.set_variant("forward", variant)
     try:
         out = MSDA.ms_deform_attn_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], 64)
     finally:
@@ -199,8 +202,9 @@ def test_tiled_forward_vs_oracle(levels, flavour, dev, api):
     assert max_abs(_np(out), ref) < 1e-4
 
 
-@pytest.mark.parametrize("M,L,P", [(1, 1, 4), (3, 2, 2), (8, 4, 2), (5, 1, 16), (2, 3, 5)])
-def test_tiled_forward_head_point_counts(M, L, P, dev, api):
+@pytest.mark.parametrize("variant", TILED_VARIANTS)
+@pytest.mark.parametrize("M,L,P", [(1, 1, 4), (3, 2, 4), (16, 3, 4), (8, 4, 2), (5, 1, 16), (2, 3, 5)])
+def test_tiled_forward_head_point_counts(M, L, P, variant, dev, api):
     from oracle import msda_oracle
     from uninext_amd import workloads
     MSDA, lib = api
@@ -208,12 +212,12 @@ def test_tiled_forward_head_point_counts(M, L, P, dev, api):
     x = workloads.make_inputs("encoder", "model", batch=1, levels=levels, heads=M, points=P, seed=9, device=dev)
     x["loc"][0, 3, 0, 0, 0, 0] = float("nan")
     x["loc"][0, 5, M - 1, L - 1, P - 1, 1] = float("inf")
-    lib.set_variant("forward", "msda_fwd_tiled")
+    lib.set_variant("forward", variant)
     try:
         out = MSDA.ms_deform_attn_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], 64)
     finally:
         lib.set_variant("forward", "auto")
-    assert lib.last_kernel("forward") == ("msda_fwd_tiled" if L * P <= 16 else "msda_fwd_lanegroup")
+    assert lib.last_kernel("forward") == ("msda_fwd_tiled" if P == 4 else "msda_fwd_lanegroup")  # P != 4 falls back
     ref = msda_oracle.forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
     assert torch.isfinite(out).all() and max_abs(_np(out), ref) < 1e-4
 

@@ -39,20 +39,31 @@ def main():
     ap.add_argument("--flavours", default="model,uniform")
     ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--no-bwd", action="store_true")
+    ap.add_argument("--sigma", type=float, default=1.0)
+    ap.add_argument("--far", type=float, default=0.05)
+    ap.add_argument("--rotate", type=int, default=1, help="cycle through this many distinct input sets (cold caches)")
     args = ap.parse_args()
     _lib.load()
     vf = [int(v) for v in args.variants_fwd.split(",") if v] or list(range(1, len(_lib.variants("forward"))))
     vb = [int(v) for v in args.variants_bwd.split(",") if v] or list(range(1, len(_lib.variants("backward"))))
     for kind in args.kinds.split(","):
         for flavour in args.flavours.split(","):
-            x = workloads.make_inputs(kind, flavour, batch=args.batch, seed=1)
+            xs = [workloads.make_inputs(kind, flavour, batch=args.batch, seed=1 + r, offset_sigma=args.sigma,
+                                        far_fraction=args.far) for r in range(args.rotate)]
+            x = xs[0]
             N, S = x["value"].shape[:2]
             Lq = x["loc"].shape[1]
             a = (x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
+            sets = [(y["value"], y["shapes"], y["lsi"], y["loc"], y["attn"]) for y in xs]
             fb = workloads.algorithmic_bytes_forward(N, S, Lq)
+            counter = [0]
+
+            def fwd_rot():
+                counter[0] += 1
+                return ext.ms_deform_attn_forward(*sets[counter[0] % len(sets)], 64)
             for v in vf:
                 _lib.set_variant("forward", v)
-                us = timeit(lambda: ext.ms_deform_attn_forward(*a, 64), args.reps)
+                us = timeit(fwd_rot, args.reps)
                 print("fwd %-8s %-8s %-22s %9.1f us  %8.1f GB/s  %5.1f%% of 8TB/s" % (
                     kind, flavour, _lib.last_kernel("forward") + "#%d" % v, us, fb / us / 1e3, fb / us / 1e3 / 80), flush=True)
             _lib.set_variant("forward", 0)

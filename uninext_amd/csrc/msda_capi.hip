@@ -17,8 +17,8 @@ thread_local const char* g_last_kernel[2] = {"", ""};
 std::atomic<int> g_variant[2] = {{-1}, {-1}};  // -1: not initialised (read env once)
 
 const char* const kVariantNames[2][msda::kNumVariants] = {
-    {"auto", "msda_fwd_generic", "msda_fwd_lanegroup", "msda_fwd_tiled"},
-    {"auto", "msda_bwd_generic", "msda_bwd_lanegroup", "msda_bwd_lanegroup"},
+    {"auto", "msda_fwd_generic", "msda_fwd_lanegroup", "msda_fwd_tiled", "msda_fwd_tiled_l0", "msda_fwd_tiled_l0big"},
+    {"auto", "msda_bwd_generic", "msda_bwd_lanegroup", "msda_bwd_lanegroup", "msda_bwd_lanegroup", "msda_bwd_lanegroup"},
 };
 
 int current_variant(int which) {

@@ -80,11 +80,11 @@ int launch_backward(int variant, const T* grad_out, const T* value, const int64_
                     hipStream_t stream, const char** kernel_name);
 
 // Variant numbering shared with include/msda_hip.h.
-enum Variant { kAuto = 0, kGeneric = 1, kLaneGroup = 2, kTiled = 3, kNumVariants = 4 };
+enum Variant { kAuto = 0, kGeneric = 1, kLaneGroup = 2, kTiled = 3, kTiledL0 = 4, kTiledL0Big = 5, kNumVariants = 6 };
 
 // msda_fwd_tiled.hip: LDS-tiled encoder forward (fp32, D = 32, Lq == S).
 bool tiled_forward_ok(const Dims& d);
-int launch_forward_tiled(const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc,
+int launch_forward_tiled(int flavour, const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc,
                          const float* attn, const Dims& d, float* out, hipStream_t stream);
 
 }  // namespace msda

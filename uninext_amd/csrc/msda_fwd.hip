@@ -199,11 +199,11 @@ int launch_forward<float>(int variant, const float* value, const int64_t* shapes
   const bool tl = tiled_forward_ok(d);
   // the tiled kernel is selected automatically only once it beats the lane-group kernel (kbench A/B)
   if (variant == kAuto) variant = (kTiledIsDefault && tl && d.S >= 4096) ? kTiled : (lg ? kLaneGroup : kGeneric);
-  if (variant == kTiled && !tl) variant = lg ? kLaneGroup : kGeneric;
+  if (variant >= kTiled && !tl) variant = lg ? kLaneGroup : kGeneric;
   if (variant == kLaneGroup && !lg) variant = kGeneric;
-  if (variant == kTiled) {
+  if (variant >= kTiled) {
     *kernel_name = "msda_fwd_tiled";
-    return launch_forward_tiled(value, shapes, lsi, loc, attn, d, out, stream);
+    return launch_forward_tiled(variant - kTiled, value, shapes, lsi, loc, attn, d, out, stream);
   }
   if (variant == kLaneGroup) {
     const int LP = d.L * d.P;

@@ -1,84 +1,91 @@
-// msda_fwd_tiled -- LDS-tiled MSDeformAttn forward for encoder-style calls (Lq == S: every pixel of the
-// pyramid is a query, raster order per level), fp32, D = 32, L <= 4, L*P <= 16.  gfx950 only.
+// msda_fwd_tiled -- LDS-window MSDeformAttn forward for encoder-style calls (Lq == S: every pixel of the
+// pyramid is a query, raster order per level).  fp32, D = 32, P = 4, L <= 4.  gfx950 only.
 //
-// Why: the 4-corner x 16-sample gather moves 8 KB per (query, head) for 128 B of output; through the
-// vector L1 (64 B/clk/CU) that alone costs > 70 us per encoder call at the R50 shapes, 3-4x the HBM time of
-// the compulsory bytes.  LDS delivers 256 B/clk/CU, so the sampled neighbourhood is staged in LDS:
+// Why: the 4-corner x 16-sample gather moves 8 KB per (query, head) for 128 B of output.  Through the
+// vector L1 alone (msda_fwd_lanegroup) the kernel is TA/L1-bound: rocprof shows 40 M 64-byte TCP accesses
+// per encoder call = ~75 us at 64 B/clk/CU, 3x the HBM time of the compulsory bytes.  LDS delivers
+// 256 B/clk/CU, so the neighbourhood the queries of a tile look at is staged in LDS and read from there,
+// optionally keeping the finest level on the L1 path so that BOTH pipes carry gather traffic.
 //
-//   work item = (image b, head m, 8x8 tile of level-0 pixels).  The tile's queries are the pixels of EVERY
-//   level whose centre falls into the tile's normalised rectangle (a partition of all S queries).  For each
-//   level a WH x WW window of head m's value rows (128 B per pixel) around the tile is copied into LDS; the
-//   window position follows the mean sampling offset of the tile's own queries (deformable-attention heads
-//   look in a preferred direction), measured from the data.  Samples whose corners fall inside a window
-//   are read from LDS; the rest (far offsets) take raw buffer loads -- correctness never depends on the
-//   window heuristics, and the tile partition does not assume anything about where queries look.
+//   work item = (image b, head m, TH x TW tile of level-0 pixels).  The tile's queries are the pixels of
+//   EVERY level whose centre falls into the tile's normalised rectangle (an exact partition of all S
+//   queries, integer arithmetic).  For every windowed level a WH x WW block of head m's value rows (128 B
+//   per pixel) is copied into LDS.  The window is placed where this head's samples actually fall: the
+//   setup code accumulates the mean offset of the samples from the tile centre and the NEXT tile of the
+//   same head (persistent workgroups stay on one head) centres its windows there.  A sample whose corners
+//   are not all inside the window ("far") is served by raw buffer loads in a second pass, so correctness
+//   never depends on the heuristics.
 //
-//   gather lane mapping (wave64 = 2 pairs x 4 corners x 8 16-byte chunks): ds_read_b128 is served in four
-//   16-lane groups {0-3,12-15,20-27} {4-11,16-19,28-31} {32-35,44-47,52-59} {36-43,48-51,60-63}
-//   (MI355X_MICROARCH.md, LDS).  Lanes are given roles such that each group reads the two x-adjacent
-//   corners of one bilinear row = 256 contiguous bytes = all 64 banks exactly once: conflict-free for any
-//   sample position.  Each lane accumulates "its" corner over the 16 samples; the four corners are summed
-//   once per query through a 1 KB LDS exchange.  Corner weights and addresses are produced once per sample
-//   by a setup role (32 lanes per pair: sample x row), parked in LDS records, re-read by the quad lane that
-//   owns the sample (4 samples per lane) and broadcast inside the quad with DPP quad_perm -- so the hot loop
-//   per sample is: v_add(dpp) address, ds_read_b128, 4 v_fmac (dpp weight).
+//   lane mapping = the lane-group mapping (8 lanes x 16 B per (query, head) pair, 8 pairs per wave, each
+//   lane accumulates 4 channels over all 64 corner reads -- no cross-lane reduction, 16-byte coalesced
+//   stores), with two twists for the LDS: (1) lanes are assigned to (pair, chunk) roles such that each of
+//   the four 16-lane groups that serve a ds_read_b128 ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32; see
+//   MI355X_MICROARCH.md) holds exactly two whole pairs, and (2) the two x-adjacent corners of a bilinear row
+//   (adjacent 128-byte LDS slots, opposite slot parity) are read in slot-parity order, even slot first for
+//   the first pair of a group and odd slot first for the second.  The two pixels a group reads in one
+//   instruction therefore always cover all 64 banks once: conflict-free for any sample position.
 //
-// A persistent grid (2 workgroups per CU, ~77 KB LDS each) walks the items head-minor, so that (observed
-// block->XCD round-robin) XCD x keeps working on head x.  All geometry is derived on the device from the
-// int64 shape tensors: the host never needs the level shapes (no sync, graph-capturable).
+// All geometry comes from the int64 shape tensors on the device: the host never needs the level shapes
+// (no sync, graph-capturable).  The grid is persistent (2 workgroups per CU) and walks the items
+// head-minor, so a workgroup -- and, by the observed round-robin, an XCD -- stays on one head.
 #include "msda_common.hpp"
 
 namespace msda {
 
-constexpr int kTile = 8;                       // level-0 pixels per tile side
-constexpr int kWinSlots = 576;                 // 72 KiB of 128-byte pixel slots for the windows
 constexpr int kTiledMaxL = 4;
+constexpr int kTiledP = 4;
 constexpr int kTiledLP = 16;
-constexpr int kMaxTileQ = 128;                 // queries handled per table round
-constexpr int kRecBytes = 4 * 1024;            // 1 KiB per wave: sample records, then the corner exchange
-constexpr int kWinMargin = 7;
+constexpr int kMaxTileQ = 256;                    // queries per table round
+constexpr int kWinSlots = 448;                    // 56 KiB of 128-byte pixel slots
+constexpr int kPairRec = 16 * 32 + 16;            // 16 sample records of 32 B, padded (bank spread)
+constexpr int kWaveRec = 8 * kPairRec;            // 8 pairs per wave
+constexpr int kRecBytes = 4 * kWaveRec;
+constexpr int kStagePerLane = kWinSlots / (kBlock / 8);  // window pixels per 8-lane group
 
 struct TiledMeta {
   int H[kTiledMaxL], W[kTiledMaxL], start[kTiledMaxL];
-  int WH[kTiledMaxL], WW[kTiledMaxL], slot[kTiledMaxL];  // window geometry, constant per launch
-  int ys[kTiledMaxL], xs[kTiledMaxL], ny[kTiledMaxL], nx[kTiledMaxL], cum[kTiledMaxL + 1];
-  float gcy[kTiledMaxL], gcx[kTiledMaxL];                  // tile centre in level coordinates
-  float dev[kTiledMaxL][4];                                // sum dy, sum dx, count, unused
-  int oy[kTiledMaxL], ox[kTiledMaxL];
-  int TY, TX, nq;
+  int WH[kTiledMaxL], WW[kTiledMaxL], slot[kTiledMaxL + 1];   // window geometry, constant per launch
+  int ys[kTiledMaxL], xs[kTiledMaxL], ny[kTiledMaxL], nx[kTiledMaxL];
+  int oy[kTiledMaxL], ox[kTiledMaxL], base[kTiledMaxL];       // window origin of the current tile
+  float gcy[kTiledMaxL], gcx[kTiledMaxL];                      // tile centre in level sample coordinates
+  float dev[kTiledMaxL][2];                                    // running mean sample offset (dy, dx) of this head
+  float devacc[kTiledMaxL][4];                                 // sum dy, sum dx, count (filled by the main loop)
+  int TY, TX;
   int qtab[kMaxTileQ];
+  uint32_t slot_tab[kWinSlots];                                // (level << 28) | (row * W_level + col)
 };
 
 constexpr int kTiledLdsBytes = kWinSlots * 128 + kRecBytes + ((sizeof(TiledMeta) + 15) / 16) * 16;
+static_assert(2 * kTiledLdsBytes <= 160 * 1024, "two workgroups per CU");
+
+typedef const f32x4 __attribute__((address_space(3)))* lds_f32x4_ptr;  // 32-bit LDS address, no base add
 
 __device__ __forceinline__ int ceil_div_signed(int a, int b) {  // b > 0
   return a >= 0 ? (a + b - 1) / b : -((-a) / b);
 }
 
-typedef const f32x4 __attribute__((address_space(3)))* lds_f32x4_ptr;  // 32-bit LDS address, no base add
-
-template <int K>
-__device__ __forceinline__ int quad_bcast(int v) {  // value of lane K of the caller's quad
-  return __builtin_amdgcn_mov_dpp(v, K * 0x55, 0xF, 0xF, true);
-}
-template <int K>
-__device__ __forceinline__ float quad_bcast(float v) {
-  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), K * 0x55, 0xF, 0xF, true));
+// lanes (of one 32-lane half) that own chunk c of the four pairs of that half -- see the role table below
+__device__ __forceinline__ constexpr uint64_t chunk_owner_mask(int c) {
+  const uint64_t h = c < 4 ? ((1ull << c) | (1ull << (4 + c)) | (1ull << (16 + c)) | (1ull << (20 + c)))
+                           : ((1ull << (8 + c)) | (1ull << (4 + c)) | (1ull << (24 + c)) | (1ull << (20 + c)));
+  return h | (h << 32);
 }
 
+// TH x TW: tile in level-0 pixels.  GL: the first GL levels are NOT windowed (raw buffer loads through L1).
+template <int TH, int TW, int GL>
 __global__ void __launch_bounds__(kBlock, 2)
 msda_fwd_tiled(const float* __restrict__ value, const int64_t* __restrict__ shapes,
                const int64_t* __restrict__ lsi, const float* __restrict__ loc,
                const float* __restrict__ attn, Dims d, float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* recs_all = smem + kWinSlots * 128;
   TiledMeta& mt = *reinterpret_cast<TiledMeta*>(smem + kWinSlots * 128 + kRecBytes);
-
+  constexpr int P = kTiledP;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int L = d.L, P = d.P, LP = L * P, M = d.M;
-  char* recs = recs_all + wv * 1024;
+  const int L = d.L, LP = L * P, M = d.M;
+  const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const uint32_t rec_wave = kWinSlots * 128 + wv * kWaveRec;  // byte offset of this wave's records in smem
 
-  // ---- once per launch: level table and window geometry ---------------------------------------
+  // ---- once per launch: level table, window geometry, staging table ---------------------------
   if (tid == 0) {
     for (int l = 0; l < L; ++l) {
       mt.H[l] = (int)shapes[2 * l];
@@ -86,20 +93,20 @@ msda_fwd_tiled(const float* __restrict__ value, const int64_t* __restrict__ shap
       mt.start[l] = (int)lsi[l];
     }
     const int H0 = mt.H[0], W0 = mt.W[0];
-    mt.TY = (H0 + kTile - 1) / kTile;
-    mt.TX = (W0 + kTile - 1) / kTile;
+    mt.TY = (H0 + TH - 1) / TH;
+    mt.TX = (W0 + TW - 1) / TW;
     int total = 0;
-    for (int margin = kWinMargin; margin >= 0; --margin) {
+    for (int margin = 10; margin >= 0; --margin) {
       total = 0;
       for (int l = 0; l < L; ++l) {
-        const int ex = (kTile * mt.W[l] + W0 - 1) / W0, ey = (kTile * mt.H[l] + H0 - 1) / H0;
-        mt.WW[l] = min(mt.W[l], ex + margin);
-        mt.WH[l] = min(mt.H[l], ey + margin);
+        const int ex = (TW * mt.W[l] + W0 - 1) / W0, ey = (TH * mt.H[l] + H0 - 1) / H0;
+        mt.WW[l] = l < GL ? 0 : min(mt.W[l], ex + margin);
+        mt.WH[l] = l < GL ? 0 : min(mt.H[l], ey + margin);
         total += mt.WW[l] * mt.WH[l];
       }
       if (total <= kWinSlots) break;
     }
-    while (total > kWinSlots) {  // odd pyramids: give up the largest window (that level goes through L1/L2)
+    while (total > kWinSlots) {  // odd pyramids: give up the largest window (that level is served through L1/L2)
       int big = 0;
       for (int l = 1; l < L; ++l)
         if (mt.WW[l] * mt.WH[l] > mt.WW[big] * mt.WH[big]) big = l;
@@ -107,30 +114,59 @@ msda_fwd_tiled(const float* __restrict__ value, const int64_t* __restrict__ shap
       mt.WW[big] = mt.WH[big] = 0;
     }
     int acc = 0;
-    for (int l = 0; l < L; ++l) {
+    for (int l = 0; l < kTiledMaxL; ++l) {
       mt.slot[l] = acc;
-      acc += mt.WW[l] * mt.WH[l];
+      if (l < L) acc += mt.WW[l] * mt.WH[l];
+      mt.dev[l][0] = mt.dev[l][1] = 0.f;
+      mt.devacc[l][0] = mt.devacc[l][1] = mt.devacc[l][2] = 0.f;
     }
+    mt.slot[kTiledMaxL] = acc;
   }
   __syncthreads();
+  const int nslots = mt.slot[kTiledMaxL];
+  for (int p = tid; p < nslots; p += kBlock) {
+    int l = 0;
+    for (int ll = 1; ll < L; ++ll)
+      if (p >= mt.slot[ll] && mt.WW[ll] > 0) l = ll;
+    const int rel = p - mt.slot[l], ww = mt.WW[l];
+    const int r = rel / ww, c = rel - r * ww;
+    mt.slot_tab[p] = ((uint32_t)l << 28) | (uint32_t)(r * mt.W[l] + c);
+  }
+  if (nslots < 2 && tid < 64) reinterpret_cast<float*>(smem)[tid] = 0.f;  // dummy reads target slots 0 / 1
+  __syncthreads();
 
-  // ---- per-lane roles ---------------------------------------------------------------------------
-  const int half = lane >> 5, t = lane & 31;
-  // setup role: sample s_set, bilinear row cy_set of this half's pair
-  const int s_set = t >> 1, cy_set = t & 1;
-  const bool s_live = s_set < LP;
-  int l_set = 0;
-  for (int l = 1; l < L; ++l) l_set += (s_set >= l * P) ? 1 : 0;
-  const int sH = mt.H[l_set], sW = mt.W[l_set], sStart = mt.start[l_set];
-  const int sWH = mt.WH[l_set], sWW = mt.WW[l_set], sSlot = mt.slot[l_set];
-  // gather role: corner (cy_g, cx_g), 16-byte chunk of the 128-byte pixel row
-  const int quad = t >> 2, k = t & 3;
-  const int cy_g = (0x96 >> quad) & 1, cx_g = (0xF0 >> quad) & 1, hf_g = (0xCC >> quad) & 1;
-  const uint32_t chunk_off = (uint32_t)(hf_g * 4 + k) * 16u;
-  const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  // ---- per-lane role: (pair of the wave, 16-byte chunk); see the header for the 16-lane groups --
+  const int t = lane & 31;
+  int pih, chunk, own_lo, own_hi;  // pair in the 32-lane half, chunk; lane owning (my pair, chunk c) = own_{lo|hi} + c
+  if (t < 4) { pih = 0; chunk = t; }
+  else if (t < 12) { pih = 2; chunk = t - 4; }
+  else if (t < 16) { pih = 0; chunk = t - 8; }
+  else if (t < 20) { pih = 3; chunk = t - 16; }
+  else if (t < 28) { pih = 1; chunk = t - 20; }
+  else { pih = 3; chunk = t - 24; }
+  if (pih == 0) { own_lo = 0; own_hi = 8; }
+  else if (pih == 2) { own_lo = 4; own_hi = 4; }
+  else if (pih == 3) { own_lo = 16; own_hi = 24; }
+  else { own_lo = 20; own_hi = 20; }
+  own_lo += lane & 32; own_hi += lane & 32;
+  const int pw = (lane >> 5) * 4 + pih;       // pair of the wave, 0..7
+  const int role_par = pih & 1;               // this pair reads the slot of this parity first
+  const uint32_t lane_off = (uint32_t)chunk * 16u;
+  const uint32_t rec_pair = rec_wave + pw * kPairRec;   // this pair's 16 records
+  // the two samples this lane prepares: s0 = 2*chunk and s0 + 1 (same level since P = 4)
+  const int s0 = 2 * chunk;
+  const int lv = min(s0 / P, L - 1);
+  const bool live = s0 < LP;
+  const int sH = mt.H[lv], sW = mt.W[lv], sStart = mt.start[lv];
+  const int sWH = mt.WH[lv], sWW = mt.WW[lv], sSlot = mt.slot[lv];
+  const bool is_gl = lv < GL;                 // this level always takes raw buffer loads in the main pass
+  const bool windowed = sWW > 0;              // false for GL levels and for levels that lost their window
+  const uint32_t dummy0 = smem_base + (uint32_t)role_par * 128u, dummy1 = smem_base + (uint32_t)(role_par ^ 1) * 128u;
+
   const int TY = mt.TY, TX = mt.TX;
   const int items = d.N * M * TY * TX;
   const uint32_t pix_bytes = (uint32_t)M * 128u;
+  const int pairs_per_image = d.Lq * M;
 
   for (int item = blockIdx.x; item < items; item += gridDim.x) {
     const int m = item % M;
@@ -138,300 +174,301 @@ msda_fwd_tiled(const float* __restrict__ value, const int64_t* __restrict__ shap
     const int b = item / (M * TY * TX);
     const int ty = tile / TX, tx = tile % TX;
 
-    // ---- P0: the tile's query rectangles per level (threads 0..L-1), then the query table ----
+    // ---- tile geometry: query rectangle and window origin per level (threads 0..L-1) -----------
     if (tid < L) {
       const int l = tid;
       const int H0 = mt.H[0], W0 = mt.W[0], Hl = mt.H[l], Wl = mt.W[l];
-      // level-l pixel x belongs to tile tx iff floor((2x+1) * W0 / (2 * kTile * Wl)) == tx
-      int xs = ceil_div_signed(tx * 2 * kTile * Wl - W0, 2 * W0);
-      int xe = ceil_div_signed((tx + 1) * 2 * kTile * Wl - W0, 2 * W0);
-      int ys = ceil_div_signed(ty * 2 * kTile * Hl - H0, 2 * H0);
-      int ye = ceil_div_signed((ty + 1) * 2 * kTile * Hl - H0, 2 * H0);
+      // level-l pixel x belongs to tile tx iff floor((2x+1) * W0 / (2 * TW * Wl)) == tx
+      int xs = ceil_div_signed(tx * 2 * TW * Wl - W0, 2 * W0);
+      int xe = ceil_div_signed((tx + 1) * 2 * TW * Wl - W0, 2 * W0);
+      int ys = ceil_div_signed(ty * 2 * TH * Hl - H0, 2 * H0);
+      int ye = ceil_div_signed((ty + 1) * 2 * TH * Hl - H0, 2 * H0);
       xs = max(0, min(xs, Wl)); xe = max(xs, min(xe, Wl));
       ys = max(0, min(ys, Hl)); ye = max(ys, min(ye, Hl));
       if (tx == TX - 1) xe = Wl;
       if (ty == TY - 1) ye = Hl;
       mt.xs[l] = xs; mt.ys[l] = ys; mt.nx[l] = xe - xs; mt.ny[l] = ye - ys;
       // centre of the tile's normalised rectangle in level-l sample coordinates (x_im = loc * W - 0.5)
-      const float x_lo = (float)(tx * kTile) / W0, x_hi = (float)min((tx + 1) * kTile, W0) / W0;
-      const float y_lo = (float)(ty * kTile) / H0, y_hi = (float)min((ty + 1) * kTile, H0) / H0;
-      mt.gcx[l] = 0.5f * (x_lo + x_hi) * Wl - 0.5f;
-      mt.gcy[l] = 0.5f * (y_lo + y_hi) * Hl - 0.5f;
-      mt.dev[l][0] = 0.f; mt.dev[l][1] = 0.f; mt.dev[l][2] = 0.f;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      int acc = 0;
-      for (int l = 0; l < L; ++l) {
-        mt.cum[l] = acc;
-        acc += mt.nx[l] * mt.ny[l];
+      const float x_lo = (float)(tx * TW) / W0, x_hi = (float)min((tx + 1) * TW, W0) / W0;
+      const float y_lo = (float)(ty * TH) / H0, y_hi = (float)min((ty + 1) * TH, H0) / H0;
+      const float gcx = 0.5f * (x_lo + x_hi) * Wl - 0.5f, gcy = 0.5f * (y_lo + y_hi) * Hl - 0.5f;
+      mt.gcx[l] = gcx; mt.gcy[l] = gcy;
+      // fold the previous tile's sample statistics into the running offset of this head
+      if (mt.devacc[l][2] > 0.f) {
+        mt.dev[l][0] = mt.devacc[l][0] / mt.devacc[l][2];
+        mt.dev[l][1] = mt.devacc[l][1] / mt.devacc[l][2];
       }
-      for (int l = L; l <= kTiledMaxL; ++l) mt.cum[l] = acc;
-      mt.nq = acc;
+      mt.devacc[l][0] = mt.devacc[l][1] = mt.devacc[l][2] = 0.f;
+      // bilinear touches floor(c) and floor(c) + 1: centre the window on c + 0.5
+      const int oy = (int)floorf(gcy + mt.dev[l][0] + 1.0f - 0.5f * (float)mt.WH[l]);
+      const int ox = (int)floorf(gcx + mt.dev[l][1] + 1.0f - 0.5f * (float)mt.WW[l]);
+      const int oyc = max(0, min(oy, Hl - mt.WH[l])), oxc = max(0, min(ox, Wl - mt.WW[l]));
+      mt.oy[l] = oyc; mt.ox[l] = oxc;
+      mt.base[l] = mt.start[l] + oyc * Wl + oxc;
     }
     __syncthreads();
-    const int nq = mt.nq;
+    int cum[kTiledMaxL + 1];
+    cum[0] = 0;
+#pragma unroll
+    for (int l = 0; l < kTiledMaxL; ++l) cum[l + 1] = cum[l] + (l < L ? mt.nx[l] * mt.ny[l] : 0);
+    const int nq = cum[kTiledMaxL];
+
+    const __amdgpu_buffer_rsrc_t vsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(value) + (int64_t)b * d.S * M * 32, 0, (int)((uint32_t)d.S * pix_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t lsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(loc) + (int64_t)b * pairs_per_image * (2 * LP), 0,
+        (int)((uint32_t)pairs_per_image * (uint32_t)(LP * 8)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t asrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(attn) + (int64_t)b * pairs_per_image * LP, 0,
+        (int)((uint32_t)pairs_per_image * (uint32_t)(LP * 4)), 0x00020000);
+    const uint32_t hoff = (uint32_t)m * 128u;
+
+    // ---- copy the windows of head m into LDS: all loads first, then the stores --------------------
+    {
+      const int c8 = tid & 7;
+      const int b0 = mt.base[0], b1 = mt.base[1], b2 = mt.base[2], b3 = mt.base[3];
+      f32x4 sv[kStagePerLane];
+#pragma unroll
+      for (int j = 0; j < kStagePerLane; ++j) {
+        const int p = (tid >> 3) + j * (kBlock / 8);
+        sv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p < nslots) {
+          const uint32_t e = mt.slot_tab[p];
+          const uint32_t l = e >> 28;
+          const int base = l == 0 ? b0 : (l == 1 ? b1 : (l == 2 ? b2 : b3));
+          const uint32_t gpix = (uint32_t)base + (e & 0x0fffffffu);
+          sv[j] = buffer_load_f32x4(vsrc, gpix * pix_bytes + (uint32_t)c8 * 16u, hoff);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < kStagePerLane; ++j) {
+        const int p = (tid >> 3) + j * (kBlock / 8);
+        if (p < nslots) *reinterpret_cast<f32x4*>(smem + p * 128 + c8 * 16) = sv[j];
+      }
+    }
+
+    const int oy = mt.oy[lv], ox = mt.ox[lv];
+    const float gcy = mt.gcy[lv], gcx = mt.gcx[lv];
+    float dsum_y = 0.f, dsum_x = 0.f, dsum_n = 0.f;
 
     for (int qbase = 0; qbase < nq; qbase += kMaxTileQ) {
       const int nround = min(kMaxTileQ, nq - qbase);
-      if (tid < nround) {
+      if (tid < nround) {  // query table of this round
         const int qi = qbase + tid;
         int l = 0;
-        for (int ll = 1; ll < L; ++ll) l += (qi >= mt.cum[ll]) ? 1 : 0;
-        const int j = qi - mt.cum[l], nx = mt.nx[l];
+#pragma unroll
+        for (int ll = 1; ll < kTiledMaxL; ++ll) l += (qi >= cum[ll]) ? 1 : 0;
+        const int j = qi - (l == 0 ? cum[0] : (l == 1 ? cum[1] : (l == 2 ? cum[2] : cum[3])));
+        const int nx = mt.nx[l];
         const int yy = (int)(((float)j + 0.5f) / (float)nx);
         const int xx = j - yy * nx;
         mt.qtab[tid] = mt.start[l] + (mt.ys[l] + yy) * mt.W[l] + mt.xs[l] + xx;
       }
-      __syncthreads();
+      __syncthreads();  // windows (first round) and table are ready
 
-      // ---- P1: where do this tile's queries look?  mean (clamped) deviation from the tile centre ----
-      if (qbase == 0) {
-        const int l = tid & 3, i = tid >> 2;  // 64 query slots x 4 levels
-        float sy = 0.f, sx = 0.f, sn = 0.f;
-        if (l < L) {
-          const int qloc = (i * nround) >> 6;
-          const int64_t pair = ((int64_t)b * d.Lq + mt.qtab[qloc]) * M + m;
-          const float* lp = loc + (pair * LP + l * P) * 2;
-          const float Hl = (float)mt.H[l], Wl = (float)mt.W[l], gy = mt.gcy[l], gx = mt.gcx[l];
-          for (int p = 0; p < P; ++p) {
-            const float x = lp[2 * p] * Wl - 0.5f, y = lp[2 * p + 1] * Hl - 0.5f;
-            const float dx = x - gx, dy = y - gy;
-            if (fabsf(dx) <= 12.f && fabsf(dy) <= 12.f) {  // ignore far-away points (and NaNs)
-              sx += dx; sy += dy; sn += 1.f;
-            }
-          }
-        }
-#pragma unroll
-        for (int o = 4; o < 64; o <<= 1) {
-          sy += __shfl_xor(sy, o, 64);
-          sx += __shfl_xor(sx, o, 64);
-          sn += __shfl_xor(sn, o, 64);
-        }
-        if (lane < L) {
-          atomicAdd(&mt.dev[lane][0], sy);
-          atomicAdd(&mt.dev[lane][1], sx);
-          atomicAdd(&mt.dev[lane][2], sn);
-        }
-        __syncthreads();
-        if (tid < L) {
-          const int l = tid;
-          const float n = fmaxf(mt.dev[l][2], 1.f);
-          const float cy = mt.gcy[l] + mt.dev[l][0] / n, cx = mt.gcx[l] + mt.dev[l][1] / n;
-          // window covers [o, o + W?) pixels; bilinear touches floor(c) and floor(c)+1 -> centre on c + 0.5
-          const int oy = (int)floorf(cy + 1.0f - 0.5f * (float)mt.WH[l]);
-          const int ox = (int)floorf(cx + 1.0f - 0.5f * (float)mt.WW[l]);
-          mt.oy[l] = max(0, min(oy, mt.H[l] - mt.WH[l]));
-          mt.ox[l] = max(0, min(ox, mt.W[l] - mt.WW[l]));
-        }
-        __syncthreads();
-
-        // ---- P3: copy the windows of head m into LDS (8 lanes x 16 B per pixel) --------------------
-        const __amdgpu_buffer_rsrc_t vsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(value) + (int64_t)b * d.S * M * 32, 0, (int)((uint32_t)d.S * pix_bytes), 0x00020000);
-        const uint32_t hoff = (uint32_t)m * 128u;
-        const int nslots = mt.slot[L - 1] + mt.WW[L - 1] * mt.WH[L - 1];
-        const int c8 = tid & 7;
-        // all loads of the window copy are issued before the first LDS store (one memory latency per tile):
-        // kWinSlots / 32 = 18 pixel slots per 8-lane group, 72 transient VGPRs
-        constexpr int kStage = kWinSlots / (kBlock / 8);
-        f32x4 sv[kStage];
-#pragma unroll
-        for (int j = 0; j < kStage; ++j) {
-          const int p = (tid >> 3) + j * (kBlock / 8);
-          sv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (p < nslots) {
-            // the last level whose slot offset is <= p and whose window is non-empty (dropped levels share
-            // their slot offset with the successor)
-            int l = 0;
-            for (int ll = 1; ll < L; ++ll)
-              if (p >= mt.slot[ll] && mt.WW[ll] > 0) l = ll;
-            const int rel = p - mt.slot[l], ww = mt.WW[l];
-            const int r = (int)(((float)rel + 0.5f) / (float)ww);
-            const int c = rel - r * ww;
-            const uint32_t gpix = (uint32_t)(mt.start[l] + (mt.oy[l] + r) * mt.W[l] + mt.ox[l] + c);
-            sv[j] = buffer_load_f32x4(vsrc, gpix * pix_bytes + (uint32_t)c8 * 16u, hoff);
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < kStage; ++j) {
-          const int p = (tid >> 3) + j * (kBlock / 8);
-          if (p < nslots) *reinterpret_cast<f32x4*>(smem + p * 128 + c8 * 16) = sv[j];
-        }
-        __syncthreads();
-      }
-
-      // ---- P4: the tile's (query, head m) pairs, two per wave per iteration ------------------------
-      const __amdgpu_buffer_rsrc_t vsrc = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<float*>(value) + (int64_t)b * d.S * M * 32, 0, (int)((uint32_t)d.S * pix_bytes), 0x00020000);
-      const uint32_t hoff = (uint32_t)m * 128u;
-      const int oy = mt.oy[l_set], ox = mt.ox[l_set];
-      const int niter = (nround + 7) >> 3;
-
-      auto pair_of = [&](int it) -> int64_t {  // -1 when this half has no query in iteration `it`
-        const int qi = it * 8 + wv * 2 + half;
-        if (qi >= nround) return -1;
-        return ((int64_t)b * d.Lq + mt.qtab[qi]) * M + m;
+      const int niter = (nround + 31) >> 5;   // 32 pairs per workgroup iteration (8 per wave)
+      auto pair_of = [&](int it) -> int {     // pair index inside image b, -1 when this lane group idles
+        const int qi = it * 32 + wv * 8 + pw;
+        return qi < nround ? mt.qtab[qi] * M + m : -1;
       };
-      float2 cur_loc = make_float2(0.f, 0.f);
-      float cur_a = 0.f;
-      int64_t cur_pair = pair_of(0);
-      if (cur_pair >= 0 && s_live) {
-        cur_loc = *reinterpret_cast<const float2*>(loc + (cur_pair * LP + s_set) * 2);
-        cur_a = attn[cur_pair * LP + s_set];
-      }
+      auto load_samples = [&](int pair, f32x4& lc, float2& at) {
+        lc = f32x4{0.f, 0.f, 0.f, 0.f};
+        at = make_float2(0.f, 0.f);
+        if (pair >= 0 && live) {
+          lc = buffer_load_f32x4(lsrc, (uint32_t)pair * (uint32_t)(LP * 8) + (uint32_t)chunk * 16u, 0);
+          const uint2 a2 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(
+              asrc, (uint32_t)pair * (uint32_t)(LP * 4) + (uint32_t)chunk * 8u, 0, 0));
+          at = make_float2(__uint_as_float(a2.x), __uint_as_float(a2.y));
+        }
+      };
+      int cur_pair = pair_of(0);
+      f32x4 cur_loc;
+      float2 cur_at;
+      load_samples(cur_pair, cur_loc, cur_at);
 
       for (int it = 0; it < niter; ++it) {
-        // prefetch the next iteration's sampling data
-        const int64_t nxt_pair = (it + 1 < niter) ? pair_of(it + 1) : -1;
-        float2 nxt_loc = make_float2(0.f, 0.f);
-        float nxt_a = 0.f;
-        if (nxt_pair >= 0 && s_live) {
-          nxt_loc = *reinterpret_cast<const float2*>(loc + (nxt_pair * LP + s_set) * 2);
-          nxt_a = attn[nxt_pair * LP + s_set];
-        }
+        const int nxt_pair = (it + 1 < niter) ? pair_of(it + 1) : -1;
+        f32x4 nxt_loc;
+        float2 nxt_at;
+        load_samples(nxt_pair, nxt_loc, nxt_at);   // prefetch: consumed in the next iteration
 
-        // -- setup role: record {w0, addr0, w1, addr1} of (sample s_set, row cy_set)
-        {
-          float w0 = 0.f, w1 = 0.f;
-          uint32_t a0 = 0u, a1 = 0u;
-          if (cur_pair >= 0 && s_live) {
-            const float x = cur_loc.x * (float)sW - 0.5f, y = cur_loc.y * (float)sH - 0.5f;
-            const bool inr = (y > -1.f) && (x > -1.f) && (y < (float)sH) && (x < (float)sW);
-            if (inr) {
-              const float yf = floorf(y), xf = floorf(x);
-              const float ly = y - yf, lx = x - xf;
-              const int yy = (int)yf + cy_set, x0 = (int)xf;
-              const float wy = (cy_set ? ly : 1.f - ly) * cur_a;
-              const bool rowok = yy >= 0 && yy <= sH - 1;
-              const bool ok0 = rowok && x0 >= 0, ok1 = rowok && x0 + 1 <= sW - 1;
-              w0 = ok0 ? wy * (1.f - lx) : 0.f;
-              w1 = ok1 ? wy * lx : 0.f;
-              const int ry = yy - oy, c0 = x0 - ox;
-              const bool rowin = (unsigned)ry < (unsigned)sWH;
-              const uint32_t lds0 = (uint32_t)(sSlot + ry * sWW + c0) * 128u;
-              const uint32_t gpix = (uint32_t)(sStart + yy * sW + x0);
-              if (ok0) a0 = (rowin && (unsigned)c0 < (unsigned)sWW) ? lds0 : (0x80000000u | (gpix * pix_bytes));
-              if (ok1)
-                a1 = (rowin && (unsigned)(c0 + 1) < (unsigned)sWW) ? lds0 + 128u
-                                                                    : (0x80000000u | ((gpix + 1u) * pix_bytes));
-              // a dead corner next to a live LDS one re-reads the live pixel (same address = broadcast)
-              if (!ok0 && ok1 && (int)a1 >= 0) a0 = a1;
-              if (!ok1 && ok0 && (int)a0 >= 0) a1 = a0;
+        // -- prepare this lane's two samples: 4 corner weights + 4 addresses each -------------------
+        bool far_flag[2] = {false, false};
+        f32x4 far_w[2];
+        u32x4 far_o[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float lx = j == 0 ? cur_loc[0] : cur_loc[2], ly = j == 0 ? cur_loc[1] : cur_loc[3];
+          const float a = j == 0 ? cur_at.x : cur_at.y;
+          f32x4 w = {0.f, 0.f, 0.f, 0.f};
+          u32x4 ad;
+          f32x4 gw = {0.f, 0.f, 0.f, 0.f};
+          u32x4 go = {kOobOffset, kOobOffset, kOobOffset, kOobOffset};
+          ad[0] = ad[2] = is_gl ? kOobOffset : dummy0;
+          ad[1] = ad[3] = is_gl ? kOobOffset : dummy1;
+          const float x = lx * (float)sW - 0.5f, y = ly * (float)sH - 0.5f;
+          const bool inr = (cur_pair >= 0) && live && (y > -1.f) && (x > -1.f) && (y < (float)sH) && (x < (float)sW);
+          if (inr) {
+            const float yf = floorf(y), xf = floorf(x);
+            const float fy = y - yf, fx = x - xf;
+            const int y0 = (int)yf, x0 = (int)xf;
+            const bool t_ok = y0 >= 0, b_ok = y0 + 1 <= sH - 1, l_ok = x0 >= 0, r_ok = x0 + 1 <= sW - 1;
+            const float wt = (1.f - fy) * a, wb = fy * a;
+            // natural order: (top,left) (top,right) (bottom,left) (bottom,right)
+            gw[0] = (t_ok && l_ok) ? wt * (1.f - fx) : 0.f;
+            gw[1] = (t_ok && r_ok) ? wt * fx : 0.f;
+            gw[2] = (b_ok && l_ok) ? wb * (1.f - fx) : 0.f;
+            gw[3] = (b_ok && r_ok) ? wb * fx : 0.f;
+            const uint32_t g00 = (uint32_t)(sStart + y0 * sW + x0) * pix_bytes;
+            go[0] = (t_ok && l_ok) ? g00 : kOobOffset;
+            go[1] = (t_ok && r_ok) ? g00 + pix_bytes : kOobOffset;
+            go[2] = (b_ok && l_ok) ? g00 + (uint32_t)sW * pix_bytes : kOobOffset;
+            go[3] = (b_ok && r_ok) ? g00 + (uint32_t)(sW + 1) * pix_bytes : kOobOffset;
+            if (is_gl) {
+              w = gw; ad = go;
+            } else {
+              const int ry = y0 - oy, cx = x0 - ox;
+              // every live corner must be inside the window
+              const bool rows_in = (!t_ok || (unsigned)ry < (unsigned)sWH) && (!b_ok || (unsigned)(ry + 1) < (unsigned)sWH);
+              const bool cols_in = (!l_ok || (unsigned)cx < (unsigned)sWW) && (!r_ok || (unsigned)(cx + 1) < (unsigned)sWW);
+              if (windowed && rows_in && cols_in) {
+                const int sl = sSlot + ry * sWW + cx;                  // slot of (top, left); may be virtual
+                const bool swap = ((sl & 1) != role_par);               // read the right column first
+                const bool swap_b = swap != ((sWW & 1) != 0);           // next row: parity flips when sWW is odd
+                const uint32_t a_tl = smem_base + (uint32_t)sl * 128u, a_bl = a_tl + (uint32_t)sWW * 128u;
+                // dead corners re-read their live row neighbour (same address) or the parity dummy
+                const uint32_t top_l = (t_ok && l_ok) ? a_tl : ((t_ok && r_ok) ? a_tl + 128u : (swap ? dummy1 : dummy0));
+                const uint32_t top_r = (t_ok && r_ok) ? a_tl + 128u : ((t_ok && l_ok) ? a_tl : (swap ? dummy0 : dummy1));
+                const uint32_t bot_l = (b_ok && l_ok) ? a_bl : ((b_ok && r_ok) ? a_bl + 128u : (swap_b ? dummy1 : dummy0));
+                const uint32_t bot_r = (b_ok && r_ok) ? a_bl + 128u : ((b_ok && l_ok) ? a_bl : (swap_b ? dummy0 : dummy1));
+                w[0] = swap ? gw[1] : gw[0]; w[1] = swap ? gw[0] : gw[1];
+                ad[0] = swap ? top_r : top_l; ad[1] = swap ? top_l : top_r;
+                w[2] = swap_b ? gw[3] : gw[2]; w[3] = swap_b ? gw[2] : gw[3];
+                ad[2] = swap_b ? bot_r : bot_l; ad[3] = swap_b ? bot_l : bot_r;
+              } else {
+                far_flag[j] = true;
+              }
+              if (j == 0 && windowed) {  // statistics for the next tile's window placement
+                const float dx = x - gcx, dy = y - gcy;
+                if (fabsf(dx) <= 12.f && fabsf(dy) <= 12.f) { dsum_x += dx; dsum_y += dy; dsum_n += 1.f; }
+              }
             }
           }
-          u32x4 rec;
-          rec[0] = __float_as_uint(w0); rec[1] = a0; rec[2] = __float_as_uint(w1); rec[3] = a1;
-          *reinterpret_cast<u32x4*>(recs + ((half * 16 + s_set) * 2 + cy_set) * 16) = rec;
+          far_w[j] = gw; far_o[j] = go;
+          *reinterpret_cast<f32x4*>(smem + rec_pair + (s0 + j) * 32) = w;
+          *reinterpret_cast<u32x4*>(smem + rec_pair + (s0 + j) * 32 + 16) = ad;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-        // -- gather role: own the records of samples k, k+4, k+8, k+12 for corner (cy_g, cx_g)
-        float rw[4], gw[4];
-        uint32_t ra[4], ga[4];
-        bool any_global = false;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const uint2 r = *reinterpret_cast<const uint2*>(recs + ((half * 16 + k + 4 * i) * 2 + cy_g) * 16 + cx_g * 8);
-          const bool g = (int)r.y < 0;
-          rw[i] = g ? 0.f : __uint_as_float(r.x);
-          ra[i] = (g ? 0u : r.y) + smem_base;  // the reader adds its own chunk offset after the broadcast
-          gw[i] = g ? __uint_as_float(r.x) : 0.f;
-          ga[i] = g ? (r.y & 0x7fffffffu) : kOobOffset;
-          any_global |= g;
-        }
-
-        // far samples first: issue their raw buffer loads now (skipped wave-uniformly per sample when no lane
-        // needs one; entries that are not flagged carry an out-of-range offset and weight 0), consume them
-        // after the LDS gather so the memory latency overlaps it
-        f32x4 fv[16];
-        const bool far = __ballot(any_global) != 0;
-        if (far) {
-#define MSDA_TILED_GLOAD(i, kk)                                                         \
-          {                                                                             \
-            const uint32_t a = (uint32_t)quad_bcast<kk>((int)ga[i]);                    \
-            fv[(i) * 4 + (kk)] = f32x4{0.f, 0.f, 0.f, 0.f};                             \
-            if (__ballot(a < kOobOffset)) fv[(i) * 4 + (kk)] = buffer_load_f32x4(vsrc, a + chunk_off, hoff); \
-          }
-#define MSDA_TILED_GROW(i) MSDA_TILED_GLOAD(i, 0) MSDA_TILED_GLOAD(i, 1) MSDA_TILED_GLOAD(i, 2) MSDA_TILED_GLOAD(i, 3)
-          MSDA_TILED_GROW(0) MSDA_TILED_GROW(1) MSDA_TILED_GROW(2) MSDA_TILED_GROW(3)
-#undef MSDA_TILED_GROW
-#undef MSDA_TILED_GLOAD
-        }
-
+        // -- gather: 16 samples x 4 corners, 16 bytes per lane per corner -----------------------------
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#define MSDA_TILED_STEP(i, kk)                                                        \
-        {                                                                             \
-          const uint32_t a = (uint32_t)quad_bcast<kk>((int)ra[i]) + chunk_off;        \
-          const float w = quad_bcast<kk>(rw[i]);                                      \
-          const f32x4 v = *reinterpret_cast<lds_f32x4_ptr>((uintptr_t)a);             \
-          acc[0] = fmaf(w, v[0], acc[0]); acc[1] = fmaf(w, v[1], acc[1]);             \
-          acc[2] = fmaf(w, v[2], acc[2]); acc[3] = fmaf(w, v[3], acc[3]);             \
-        }
-#define MSDA_TILED_ROW(i) MSDA_TILED_STEP(i, 0) MSDA_TILED_STEP(i, 1) MSDA_TILED_STEP(i, 2) MSDA_TILED_STEP(i, 3)
-        MSDA_TILED_ROW(0) MSDA_TILED_ROW(1) MSDA_TILED_ROW(2) MSDA_TILED_ROW(3)
-#undef MSDA_TILED_ROW
-#undef MSDA_TILED_STEP
-
-        if (far) {
-#define MSDA_TILED_GSTEP(i, kk)                                                       \
-          {                                                                           \
-            const float w = quad_bcast<kk>(gw[i]);                                    \
-            const f32x4 v = fv[(i) * 4 + (kk)];                                       \
-            acc[0] = fmaf(w, v[0], acc[0]); acc[1] = fmaf(w, v[1], acc[1]);           \
-            acc[2] = fmaf(w, v[2], acc[2]); acc[3] = fmaf(w, v[3], acc[3]);           \
+#pragma unroll
+        for (int s = 0; s < kTiledLP; ++s) {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(smem + rec_pair + s * 32);
+          const u32x4 ad = *reinterpret_cast<const u32x4*>(smem + rec_pair + s * 32 + 16);
+          f32x4 v0, v1, v2, v3;
+          if (s < GL * P) {
+            v0 = buffer_load_f32x4(vsrc, ad[0] + lane_off, hoff);
+            v1 = buffer_load_f32x4(vsrc, ad[1] + lane_off, hoff);
+            v2 = buffer_load_f32x4(vsrc, ad[2] + lane_off, hoff);
+            v3 = buffer_load_f32x4(vsrc, ad[3] + lane_off, hoff);
+          } else {
+            v0 = *reinterpret_cast<lds_f32x4_ptr>((uintptr_t)(ad[0] + lane_off));
+            v1 = *reinterpret_cast<lds_f32x4_ptr>((uintptr_t)(ad[1] + lane_off));
+            v2 = *reinterpret_cast<lds_f32x4_ptr>((uintptr_t)(ad[2] + lane_off));
+            v3 = *reinterpret_cast<lds_f32x4_ptr>((uintptr_t)(ad[3] + lane_off));
           }
-#define MSDA_TILED_GROW(i) MSDA_TILED_GSTEP(i, 0) MSDA_TILED_GSTEP(i, 1) MSDA_TILED_GSTEP(i, 2) MSDA_TILED_GSTEP(i, 3)
-          MSDA_TILED_GROW(0) MSDA_TILED_GROW(1) MSDA_TILED_GROW(2) MSDA_TILED_GROW(3)
-#undef MSDA_TILED_GROW
-#undef MSDA_TILED_GSTEP
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            acc[c] = fmaf(w[3], v3[c], fmaf(w[2], v2[c], fmaf(w[1], v1[c], fmaf(w[0], v0[c], acc[c]))));
         }
 
-        // -- sum the four corners through LDS (records are dead now) and store 128 B per pair
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        *reinterpret_cast<f32x4*>(recs + ((half * 4 + cy_g * 2 + cx_g) * 8 + hf_g * 4 + k) * 16) = acc;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (t < 8 && cur_pair >= 0) {
-          const char* e = recs + (half * 4 * 8 + t) * 16;
-          const f32x4 s0 = *reinterpret_cast<const f32x4*>(e), s1 = *reinterpret_cast<const f32x4*>(e + 128);
-          const f32x4 s2 = *reinterpret_cast<const f32x4*>(e + 256), s3 = *reinterpret_cast<const f32x4*>(e + 384);
-          *reinterpret_cast<f32x4*>(out + cur_pair * 32 + t * 4) = (s0 + s1) + (s2 + s3);
+        // -- far samples (corners outside the window): raw buffer loads in a second pass --------------
+        const uint64_t far0 = __ballot(far_flag[0]), far1 = __ballot(far_flag[1]);
+        if (far0 | far1) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            if (far_flag[j]) {  // the main record of a far sample had all-zero weights: replace it
+              *reinterpret_cast<f32x4*>(smem + rec_pair + (s0 + j) * 32) = far_w[j];
+              *reinterpret_cast<u32x4*>(smem + rec_pair + (s0 + j) * 32 + 16) = far_o[j];
+            }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+          for (int s = GL * P; s < kTiledLP; ++s) {
+            const uint64_t fm = (s & 1) ? far1 : far0;   // bit = lane that prepared the sample
+            const int c = s >> 1;
+            if (fm & chunk_owner_mask(c)) {               // wave-uniform: some pair has sample s far
+              const int owner = (c < 4 ? own_lo : own_hi) + c;
+              if ((fm >> owner) & 1ull) {                 // my pair's sample s is far
+                const f32x4 w = *reinterpret_cast<const f32x4*>(smem + rec_pair + s * 32);
+                const u32x4 ad = *reinterpret_cast<const u32x4*>(smem + rec_pair + s * 32 + 16);
+                const f32x4 v0 = buffer_load_f32x4(vsrc, ad[0] + lane_off, hoff);
+                const f32x4 v1 = buffer_load_f32x4(vsrc, ad[1] + lane_off, hoff);
+                const f32x4 v2 = buffer_load_f32x4(vsrc, ad[2] + lane_off, hoff);
+                const f32x4 v3 = buffer_load_f32x4(vsrc, ad[3] + lane_off, hoff);
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc)
+                  acc[cc] = fmaf(w[3], v3[cc], fmaf(w[2], v2[cc], fmaf(w[1], v1[cc], fmaf(w[0], v0[cc], acc[cc]))));
+              }
+            }
+          }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
 
-        cur_pair = nxt_pair; cur_loc = nxt_loc; cur_a = nxt_a;
+        if (cur_pair >= 0)
+          *reinterpret_cast<f32x4*>(out + ((int64_t)b * pairs_per_image + cur_pair) * 32 + chunk * 4) = acc;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();   // records are rewritten by the next iteration
+
+        cur_pair = nxt_pair; cur_loc = nxt_loc; cur_at = nxt_at;
       }
-      __syncthreads();  // windows / table are rewritten by the next round or item
+      __syncthreads();  // table / windows are rewritten by the next round or item
     }
+
+    // sample statistics of this tile -> window placement of the next one (same head)
+    if (windowed && dsum_n > 0.f) {
+      atomicAdd(&mt.devacc[lv][0], dsum_y);
+      atomicAdd(&mt.devacc[lv][1], dsum_x);
+      atomicAdd(&mt.devacc[lv][2], dsum_n);
+    }
+    __syncthreads();
   }
 }
 
 // Host side ---------------------------------------------------------------------------------------
 bool tiled_forward_ok(const Dims& d) {
-  return d.D == 32 && d.L <= kTiledMaxL && d.L * d.P <= kTiledLP && d.Lq == d.S &&
-         (int64_t)d.S * d.M * 128 < (int64_t)kOobOffset && (int64_t)d.N * d.Lq * d.M < ((int64_t)1 << 40);
+  return d.D == 32 && d.P == kTiledP && d.L <= kTiledMaxL && d.Lq == d.S &&
+         (int64_t)d.S * d.M * 128 < (int64_t)kOobOffset && d.N <= 65535;
 }
 
-int launch_forward_tiled(const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc,
-                         const float* attn, const Dims& d, float* out, hipStream_t stream) {
+template <int TH, int TW, int GL>
+static int launch_tiled(const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc,
+                        const float* attn, const Dims& d, float* out, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in; idempotent, not a stream operation
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_fwd_tiled),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_fwd_tiled<TH, TW, GL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kTiledLdsBytes);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   // persistent grid: 2 workgroups per CU on 256 CUs, a multiple of 8 so that item % M tracks blockIdx % 8
-  const unsigned grid = 512;
-  hipLaunchKernelGGL(msda_fwd_tiled, dim3(grid), dim3(kBlock), kTiledLdsBytes, stream, value, shapes, lsi, loc, attn, d,
-                     out);
+  hipLaunchKernelGGL((msda_fwd_tiled<TH, TW, GL>), dim3(512), dim3(kBlock), kTiledLdsBytes, stream, value, shapes, lsi,
+                     loc, attn, d, out);
   return (int)hipGetLastError();
+}
+
+int launch_forward_tiled(int flavour, const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc,
+                         const float* attn, const Dims& d, float* out, hipStream_t stream) {
+  switch (flavour) {
+    case 1: return launch_tiled<8, 16, 1>(value, shapes, lsi, loc, attn, d, out, stream);   // level 0 through L1
+    case 2: return launch_tiled<16, 16, 1>(value, shapes, lsi, loc, attn, d, out, stream);
+    default: return launch_tiled<8, 8, 0>(value, shapes, lsi, loc, attn, d, out, stream);   // every level in LDS
+  }
 }
 
 }  // namespace msda

@@ -49,7 +49,7 @@ def encoder_reference_points(levels, device):
 
 def make_inputs(kind="encoder", flavour="model", batch=2, levels=R50_LEVELS_INFER, num_query=None, heads=HEADS,
                 head_dim=HEAD_DIM, points=POINTS, seed=0, device="cuda", dtype=torch.float32, value_scale=1.0,
-                offset_sigma=1.0):
+                offset_sigma=1.0, far_fraction=0.05):
     """Returns dict(value, shapes, lsi, loc, attn) on `device`; generation is seeded and device-independent
     (drawn on CPU, then moved)."""
     g = torch.Generator().manual_seed(seed)
@@ -73,7 +73,7 @@ def make_inputs(kind="encoder", flavour="model", batch=2, levels=R50_LEVELS_INFE
                 ref = ref[torch.randint(0, S, (Lq,), generator=g)]
             wh = torch.tensor([[w, h] for h, w in levels], dtype=torch.float32).view(1, 1, 1, L, 1, 2)
             loc = ref.view(1, Lq, 1, 1, 1, 2) + offsets / wh
-            far = torch.rand(batch, Lq, heads, L, points, 1, generator=g) < 0.05
+            far = torch.rand(batch, Lq, heads, L, points, 1, generator=g) < far_fraction
             loc = torch.where(far, loc + torch.sign(loc - 0.5) * 0.75, loc)
         else:
             cxcy = torch.rand(batch, Lq, 1, 1, 1, 2, generator=g)
