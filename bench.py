@@ -53,7 +53,8 @@ def parse_args():
                     help="sampling-location distribution (SURVEY.md 8(d)); 'model' is the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-bytes", type=float, default=None,
-                    help="HBM bytes per encoder launch from a separate rocprofv3 --pmc pass (see profiles/README.md)")
+                    help="HBM bytes per encoder launch from a separate rocprofv3 --pmc pass; default: the committed "
+                         "profiles/traffic.json entry for the kernel that ran (see profiles/README.md)")
     return ap.parse_args()
 
 
@@ -109,28 +110,48 @@ def run_step(enc, dec, ev=None):
         call(x)
 
 
+def committed_traffic(kernel):
+    """PMC counters cannot be collected inside the timed run; the last committed PMC pass of the same command is
+    the source (profiles/traffic.json), only used when it was taken on the kernel that ran here."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        return float(rec["traffic_bytes_per_launch"]) if rec.get("kernel") == kernel else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def cpu_baseline(flavour):
     """Bounded sample of the same workload on the host: one encoder call and one decoder call of the
-    reference's grid_sample path (N = 2), 1 warm-up + 3 timed each; a step is 6 of each."""
+    reference's grid_sample path (N = 2); a step is 6 of each.  grid_sample's OpenMP scaling collapses when
+    oversubscribed, so two thread counts are tried (all logical cores, and 64 when the box has more) and the
+    faster one is reported together with the thread count it used."""
     from oracle.msda_gridsample import msda_gridsample
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    per_step = 0.0
-    for kind, layers in (("encoder", ENC_LAYERS), ("decoder", DEC_LAYERS)):
+    ncpu = os.cpu_count() or 1
+    inputs = {}
+    for kind in ("encoder", "decoder"):
         x = workloads.make_inputs(kind, flavour, batch=BATCH, seed=7, device="cpu")
-        shapes = [tuple(r) for r in x["shapes"].tolist()]
+        inputs[kind] = (x, [tuple(r) for r in x["shapes"].tolist()])
+    best = None
+    for threads in sorted({ncpu, min(ncpu, 64)}, reverse=True):
+        torch.set_num_threads(threads)
+        per_step = 0.0
         with torch.no_grad():
-            msda_gridsample(x["value"], shapes, x["loc"], x["attn"])
-            ts = []
-            for _ in range(3):
-                t0 = time.perf_counter()
+            for kind, layers in (("encoder", ENC_LAYERS), ("decoder", DEC_LAYERS)):
+                x, shapes = inputs[kind]
                 msda_gridsample(x["value"], shapes, x["loc"], x["attn"])
-                ts.append(time.perf_counter() - t0)
-        per_step += layers * sorted(ts)[1]
-    return {"value": BATCH / per_step, "unit": "frames/s", "cores": cores, "kind": "port",
+                ts = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    msda_gridsample(x["value"], shapes, x["loc"], x["attn"])
+                    ts.append(time.perf_counter() - t0)
+                per_step += layers * sorted(ts)[1]
+        if best is None or per_step < best[0]:
+            best = (per_step, threads)
+    per_step, threads = best
+    return {"value": BATCH / per_step, "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": "median of 3 runs (after 1 warm-up) of ONE encoder call and ONE decoder call at N=2, "
                       "x6 each per step; oracle/msda_gridsample.py (= ms_deform_attn_core_pytorch), fp32, "
-                      "torch.set_num_threads(%d)" % cores}
+                      "torch.set_num_threads(%d) of %d logical cores (faster of the thread counts tried)" % (threads, ncpu)}
 
 
 def main():
@@ -183,7 +204,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": args.traffic_bytes,
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": args.traffic_bytes if args.traffic_bytes is not None else committed_traffic(enc_kernel),
                 "kernel": enc_kernel, "launch_us": 1e3 * enc_ms, "algorithmic_bytes": alg_bytes,
             },
         }

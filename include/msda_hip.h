@@ -97,8 +97,8 @@ int msda_hip_get_variant(int which);
 const char* msda_hip_variant_name(int which, int variant); /* NULL past the last variant */
 
 /*
- * Name of the kernel the last forward (which = 0) / backward (which = 1) call on this
- * thread actually launched -- lets tests assert that the intended HIP path ran.
+ * Name of the kernel the last forward (which = 0) / backward (which = 1) call of this
+ * process actually launched -- lets tests assert that the intended HIP path ran.
  */
 const char* msda_hip_last_kernel(int which);
 

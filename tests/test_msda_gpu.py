@@ -132,12 +132,17 @@ def test_quarter_scale_r50_vs_oracle(kind, flavour, dev, api):
     ref = msda_oracle.forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
     assert max_abs(_np(out), ref) < 1e-4
     go = torch.randn(out.shape, generator=torch.Generator().manual_seed(5)).to(dev)
-    gv, gl, ga = MSDA.ms_deform_attn_backward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], go, 64)
-    assert lib.last_kernel("backward") == "msda_bwd_lanegroup"
     ogv, ogl, oga = msda_oracle.backward(go, x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
-    assert scaled_err(_np(gv), ogv) < 1e-4
-    assert scaled_err(_np(ga), oga) < 1e-4
-    assert scaled_err(_np(gl), ogl) < 1e-3
+    for variant in ("msda_bwd_generic", "msda_bwd_lanegroup"):
+        lib.set_variant("backward", variant)
+        try:
+            gv, gl, ga = MSDA.ms_deform_attn_backward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], go, 64)
+        finally:
+            lib.set_variant("backward", "auto")
+        assert lib.last_kernel("backward") == variant
+        assert scaled_err(_np(gv), ogv) < 1e-4
+        assert scaled_err(_np(ga), oga) < 1e-4
+        assert scaled_err(_np(gl), ogl) < 1e-3
 
 
 @pytest.mark.parametrize("D,M,L,P", [(4, 3, 2, 3), (8, 5, 3, 2), (16, 2, 1, 5), (64, 2, 4, 4), (128, 1, 2, 2),
@@ -159,7 +164,11 @@ def test_lanegroup_shapes_vs_oracle(D, M, L, P, dev, api):
     assert lib.last_kernel("forward") == "msda_fwd_lanegroup"
     assert max_abs(_np(out), msda_oracle.forward(value, sh, lsi, loc, attn)) < 1e-4
     go = torch.randn(out.shape, generator=g).to(dev)
-    gv, gl, ga = MSDA.ms_deform_attn_backward(value, sh, lsi, loc, attn, go, 64)
+    lib.set_variant("backward", "msda_bwd_lanegroup")
+    try:
+        gv, gl, ga = MSDA.ms_deform_attn_backward(value, sh, lsi, loc, attn, go, 64)
+    finally:
+        lib.set_variant("backward", "auto")
     assert lib.last_kernel("backward") == "msda_bwd_lanegroup"
     ogv, ogl, oga = msda_oracle.backward(go, value, sh, lsi, loc, attn)
     assert scaled_err(_np(gv), ogv) < 1e-4 and scaled_err(_np(ga), oga) < 1e-4 and scaled_err(_np(gl), ogl) < 1e-3
@@ -273,8 +282,9 @@ def test_full_size_decoder_forward(dev, api):
     assert max_abs(_np(out), ref) < 1e-4
 
 
+@pytest.mark.parametrize("variant", ["auto", "msda_bwd_lanegroup"])
 @pytest.mark.parametrize("levels", ["infer", "train"])
-def test_full_size_encoder_backward(levels, dev, api):
+def test_full_size_encoder_backward(levels, variant, dev, api):
     from oracle import msda_oracle
     from uninext_amd import workloads
     MSDA, lib = api
@@ -283,8 +293,12 @@ def test_full_size_encoder_backward(levels, dev, api):
     S = x["value"].shape[1]
     out = MSDA.ms_deform_attn_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], 64)
     go = torch.randn(out.shape, generator=torch.Generator().manual_seed(8)).to(dev)
-    gv, gl, ga = MSDA.ms_deform_attn_backward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], go, 64)
-    assert lib.last_kernel("backward") == "msda_bwd_lanegroup"
+    lib.set_variant("backward", variant)
+    try:
+        gv, gl, ga = MSDA.ms_deform_attn_backward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], go, 64)
+    finally:
+        lib.set_variant("backward", "auto")
+    assert lib.last_kernel("backward") == ("msda_bwd_generic" if variant == "auto" else variant)
     # per-query gradients: oracle on a query subset
     idx = torch.cat([torch.arange(0, 200), torch.arange(S - 200, S),
                      torch.randint(0, S, (400,), generator=torch.Generator().manual_seed(2))]).to(dev)

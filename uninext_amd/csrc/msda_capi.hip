@@ -13,7 +13,8 @@
 namespace {
 
 thread_local char g_err[512] = "";
-thread_local const char* g_last_kernel[2] = {"", ""};
+// process-wide (autograd runs backward on its own thread); last writer wins
+std::atomic<const char*> g_last_kernel[2] = {{""}, {""}};
 std::atomic<int> g_variant[2] = {{-1}, {-1}};  // -1: not initialised (read env once)
 
 const char* const kVariantNames[2][msda::kNumVariants] = {
@@ -59,8 +60,10 @@ int forward_impl(const T* value, const int64_t* shapes, const int64_t* lsi, cons
   if (int rc = check_dims(d)) return rc;
   if (d.N == 0 || d.Lq == 0) return 0;
   if (!value || !shapes || !lsi || !loc || !attn || !out) return fail(MSDA_ERR_NULL_POINTER, "null pointer argument");
+  const char* name = "";
   const int rc = msda::launch_forward<T>(current_variant(0), value, shapes, lsi, loc, attn, d, out,
-                                         (hipStream_t)stream, &g_last_kernel[0]);
+                                         (hipStream_t)stream, &name);
+  g_last_kernel[0].store(name, std::memory_order_relaxed);
   return finish(rc, "msda_hip_forward");
 }
 
@@ -71,8 +74,10 @@ int backward_impl(const T* grad_out, const T* value, const int64_t* shapes, cons
   if (d.N == 0 || d.Lq == 0) return 0;
   if (!grad_out || !value || !shapes || !lsi || !loc || !attn || !grad_value || !grad_loc || !grad_attn)
     return fail(MSDA_ERR_NULL_POINTER, "null pointer argument");
+  const char* name = "";
   const int rc = msda::launch_backward<T>(current_variant(1), grad_out, value, shapes, lsi, loc, attn, d, grad_value,
-                                          grad_loc, grad_attn, (hipStream_t)stream, &g_last_kernel[1]);
+                                          grad_loc, grad_attn, (hipStream_t)stream, &name);
+  g_last_kernel[1].store(name, std::memory_order_relaxed);
   return finish(rc, "msda_hip_backward");
 }
 
@@ -133,6 +138,8 @@ const char* msda_hip_variant_name(int which, int variant) {
   return kVariantNames[which][variant];
 }
 
-const char* msda_hip_last_kernel(int which) { return (which < 0 || which > 1) ? "" : g_last_kernel[which]; }
+const char* msda_hip_last_kernel(int which) {
+  return (which < 0 || which > 1) ? "" : g_last_kernel[which].load(std::memory_order_relaxed);
+}
 
 }  // extern "C"
