@@ -7,8 +7,18 @@ import numpy as np
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def golden_names():
+def _names():
     return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def golden_names():
+    """MSDeformAttn operator fixtures (tests/golden/make_golden.py)."""
+    return [n for n in _names() if not n.startswith("matcher_")]
+
+
+def matcher_names():
+    """Matcher index fixtures (tests/golden/make_matcher_golden.py)."""
+    return [n for n in _names() if n.startswith("matcher_")]
 
 
 def load_golden(name):

@@ -1,0 +1,71 @@
+"""CPU: bit-exact index parity of uninext_amd.matcher.HungarianMatcherVL with the reference matcher.
+
+Fixtures (tests/golden/matcher_*.npz) were produced by running the reference's own matcher.py on seeded CPU inputs
+(tests/golden/make_matcher_golden.py); BASELINE.json asks for integer equality, so every comparison is array_equal.
+"""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import load_golden, matcher_names
+from uninext_amd.matcher import HungarianMatcherVL, box_iou, generalized_box_iou
+
+NAMES = matcher_names()
+
+
+def _case(name, device="cpu"):
+    g = load_golden(name)
+    bs = int(g["bs"])
+    outputs = {"pred_logits": torch.from_numpy(g["pred_logits"]).to(device),
+               "pred_boxes": torch.from_numpy(g["pred_boxes"]).to(device)}
+    targets = [{"boxes": torch.from_numpy(g[f"tgt_boxes_{b}"]).to(device),
+                "positive_map": torch.from_numpy(g[f"tgt_posmap_{b}"]).to(device)} for b in range(bs)]
+    return g, bs, outputs, targets
+
+
+def test_fixtures_present():
+    assert len(NAMES) >= 6
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_hungarian_indices_bit_exact(name):
+    g, bs, outputs, targets = _case(name)
+    result = HungarianMatcherVL(cost_class=2, cost_bbox=5, cost_giou=2).forward(outputs, targets)
+    assert len(result) == bs
+    for b, (i, j) in enumerate(result):
+        assert i.dtype == torch.int64 and j.dtype == torch.int64
+        assert np.array_equal(i.numpy(), g[f"hung_i_{b}"])
+        assert np.array_equal(j.numpy(), g[f"hung_j_{b}"])
+        assert len(i) == min(outputs["pred_logits"].shape[1], len(targets[b]["boxes"]))
+
+
+@pytest.mark.parametrize("name", [n for n in NAMES if "encoder" not in n])
+def test_ota_indices_bit_exact(name):
+    g, bs, outputs, targets = _case(name)
+    indices, matched = HungarianMatcherVL(cost_class=2, cost_bbox=5, cost_giou=2).forward_ota(outputs, targets)
+    for b in range(bs):
+        q, gt = indices[b]
+        assert q.dtype == torch.int64 and gt.dtype == torch.int64
+        assert np.array_equal(q.numpy(), g[f"ota_q_{b}"])
+        assert np.array_equal(gt.numpy(), g[f"ota_g_{b}"])
+        m = matched[b].numpy() if torch.is_tensor(matched[b]) else np.asarray(matched[b], dtype=np.int64)
+        assert np.array_equal(m, g[f"ota_matched_{b}"])
+        if len(targets[b]["boxes"]):
+            assert set(gt.tolist()) == set(range(len(targets[b]["boxes"])))   # every gt got at least one query
+            assert len(set(q.tolist())) == len(q)                            # a query serves one gt
+
+
+def test_box_helpers_against_closed_forms():
+    a = torch.tensor([[0.0, 0.0, 2.0, 2.0], [1.0, 1.0, 3.0, 3.0]])
+    b = torch.tensor([[1.0, 1.0, 2.0, 2.0], [4.0, 4.0, 5.0, 5.0]])
+    iou = box_iou(a, b)
+    assert torch.allclose(iou, torch.tensor([[0.25, 0.0], [0.25, 0.0]]))
+    giou = generalized_box_iou(a, b)
+    assert torch.allclose(giou[0, 1], torch.tensor(0.0 - (25.0 - 5.0) / 25.0), atol=1e-6)
+    with pytest.raises(AssertionError):
+        generalized_box_iou(torch.tensor([[1.0, 1.0, 0.0, 0.0]]), b)
+
+
+def test_constructor_rejects_all_zero_costs():
+    with pytest.raises(AssertionError):
+        HungarianMatcherVL(0, 0, 0, 0)
