@@ -133,7 +133,9 @@ def test_quarter_scale_r50_vs_oracle(kind, flavour, dev, api):
     assert max_abs(_np(out), ref) < 1e-4
     go = torch.randn(out.shape, generator=torch.Generator().manual_seed(5)).to(dev)
     ogv, ogl, oga = msda_oracle.backward(go, x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
-    for variant in ("msda_bwd_generic", "msda_bwd_lanegroup"):
+    for variant in ("msda_bwd_generic", "msda_bwd_lanegroup", "msda_bwd_tiled"):
+        if variant == "msda_bwd_tiled" and kind != "encoder":
+            continue   # the tiled backward needs Lq == S; other calls fall back to the generic kernel
         lib.set_variant("backward", variant)
         try:
             gv, gl, ga = MSDA.ms_deform_attn_backward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], go, 64)
@@ -282,7 +284,32 @@ def test_full_size_decoder_forward(dev, api):
     assert max_abs(_np(out), ref) < 1e-4
 
 
-@pytest.mark.parametrize("variant", ["auto", "msda_bwd_lanegroup"])
+@pytest.mark.parametrize("flavour", ["model", "uniform", "wide"])
+@pytest.mark.parametrize("levels", TILED_PYRAMIDS)
+def test_tiled_backward_vs_oracle(levels, flavour, dev, api):
+    """LDS-privatised backward (Lq == S) on odd pyramids: 'model' exercises the LDS accumulators, 'uniform' and
+    'wide' the far path (direct full-line global atomics)."""
+    from oracle import msda_oracle
+    from uninext_amd import workloads
+    MSDA, lib = api
+    kw = dict(offset_sigma=6.0) if flavour == "wide" else {}
+    x = workloads.make_inputs("encoder", "model" if flavour == "wide" else flavour, batch=2, levels=levels,
+                              seed=35, device=dev, **kw)
+    S = x["value"].shape[1]
+    go = torch.randn(2, S, 256, generator=torch.Generator().manual_seed(36)).to(dev)
+    lib.set_variant("backward", "msda_bwd_tiled")
+    try:
+        gv, gl, ga = MSDA.ms_deform_attn_backward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], go, 64)
+    finally:
+        lib.set_variant("backward", "auto")
+    assert lib.last_kernel("backward") == "msda_bwd_tiled"
+    ogv, ogl, oga = msda_oracle.backward(go, x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
+    assert scaled_err(_np(gv), ogv) < 1e-4
+    assert scaled_err(_np(ga), oga) < 1e-4
+    assert scaled_err(_np(gl), ogl) < 1e-3
+
+
+@pytest.mark.parametrize("variant", ["auto", "msda_bwd_lanegroup", "msda_bwd_generic"])
 @pytest.mark.parametrize("levels", ["infer", "train"])
 def test_full_size_encoder_backward(levels, variant, dev, api):
     from oracle import msda_oracle
@@ -298,7 +325,7 @@ def test_full_size_encoder_backward(levels, variant, dev, api):
         gv, gl, ga = MSDA.ms_deform_attn_backward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], go, 64)
     finally:
         lib.set_variant("backward", "auto")
-    assert lib.last_kernel("backward") == ("msda_bwd_generic" if variant == "auto" else variant)
+    assert lib.last_kernel("backward") == ("msda_bwd_tiled" if variant == "auto" else variant)
     # per-query gradients: oracle on a query subset
     idx = torch.cat([torch.arange(0, 200), torch.arange(S - 200, S),
                      torch.randint(0, S, (400,), generator=torch.Generator().manual_seed(2))]).to(dev)

@@ -45,7 +45,7 @@ def main():
     args = ap.parse_args()
     _lib.load()
     vf = [int(v) for v in args.variants_fwd.split(",") if v] or list(range(1, len(_lib.variants("forward"))))
-    vb = [int(v) for v in args.variants_bwd.split(",") if v] or list(range(1, len(_lib.variants("backward"))))
+    vb = [int(v) for v in args.variants_bwd.split(",") if v] or [1, 2, 3]
     for kind in args.kinds.split(","):
         for flavour in args.flavours.split(","):
             xs = [workloads.make_inputs(kind, flavour, batch=args.batch, seed=1 + r, offset_sigma=args.sigma,

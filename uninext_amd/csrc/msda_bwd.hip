@@ -290,13 +290,19 @@ int launch_backward<float>(int variant, const float* grad_out, const float* valu
                            const char** kernel_name) {
   int G = 0;
   const bool lg = lanegroup_ok(d, &G);
-  // Measured on MI355X (profiles/r01_kbench_first.txt): the value-gradient atomics dominate and cost one L2
-  // operation per (instruction, cache line) pair.  The generic kernel adds 128 contiguous bytes per instruction
-  // (2.0 ms per encoder call), the lane-group kernel 8 lines of 8 scattered dwords (8.2 ms) -- so `auto` takes
-  // the generic kernel until grad_value is privatised in LDS.
-  if (variant == kAuto) variant = kGeneric;
-  if (variant >= kLaneGroup && !lg) variant = kGeneric;
-  if (variant >= kLaneGroup) {
+  // Measured on MI355X (profiles/): the value-gradient atomics dominate and cost one L2 operation per
+  // (instruction, cache line) pair.  msda_bwd_generic adds 128 contiguous bytes per instruction (2.05 ms per
+  // encoder call), msda_bwd_lanegroup 8 lines of 8 scattered dwords (8.2 ms), msda_bwd_tiled combines the adds
+  // in LDS first (0.48 ms).  `auto`: tiled for encoder-style calls, generic otherwise.
+  const bool tl = tiled_backward_ok(d);
+  if (variant == kAuto) variant = (tl && d.S >= 1024) ? kTiled : kGeneric;
+  if (variant >= kTiled && !tl) variant = kGeneric;
+  if (variant >= kTiled) {
+    *kernel_name = "msda_bwd_tiled";
+    return launch_backward_tiled(grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, stream);
+  }
+  if (variant == kLaneGroup && !lg) variant = kGeneric;
+  if (variant == kLaneGroup) {
     *kernel_name = "msda_bwd_lanegroup";
 #define MSDA_BWD_CASE(GG, LL) \
   return launch_lanegroup<GG, LL>(grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, stream)

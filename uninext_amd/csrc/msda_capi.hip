@@ -19,7 +19,7 @@ std::atomic<int> g_variant[2] = {{-1}, {-1}};  // -1: not initialised (read env 
 
 const char* const kVariantNames[2][msda::kNumVariants] = {
     {"auto", "msda_fwd_generic", "msda_fwd_lanegroup", "msda_fwd_tiled", "msda_fwd_tiled_l0", "msda_fwd_tiled_l0big"},
-    {"auto", "msda_bwd_generic", "msda_bwd_lanegroup", "msda_bwd_lanegroup", "msda_bwd_lanegroup", "msda_bwd_lanegroup"},
+    {"auto", "msda_bwd_generic", "msda_bwd_lanegroup", "msda_bwd_tiled", "msda_bwd_tiled", "msda_bwd_tiled"},
 };
 
 int current_variant(int which) {

@@ -15,6 +15,7 @@ constexpr uint32_t kOobOffset = 0x80000000u;  // buffer offset that is always pa
 // typedef silently converts through a scalar splat on this compiler).
 typedef unsigned int u32x4 __attribute__((__vector_size__(16)));
 typedef float f32x4 __attribute__((__vector_size__(16)));
+typedef float f32x2 __attribute__((__vector_size__(8)));
 
 // 16-byte raw buffer load as 4 floats.  NB: never __builtin_bit_cast a single vector ELEMENT
 // (`bit_cast(float, v[i])` reads element 0 for every i on this compiler); cast the whole vector.
@@ -81,6 +82,12 @@ int launch_backward(int variant, const T* grad_out, const T* value, const int64_
 
 // Variant numbering shared with include/msda_hip.h.
 enum Variant { kAuto = 0, kGeneric = 1, kLaneGroup = 2, kTiled = 3, kTiledL0 = 4, kTiledL0Big = 5, kNumVariants = 6 };
+
+// msda_bwd_tiled.hip: backward with grad_value privatised in LDS (fp32, D = 32, P = 4, Lq == S).
+bool tiled_backward_ok(const Dims& d);
+int launch_backward_tiled(const float* grad_out, const float* value, const int64_t* shapes, const int64_t* lsi,
+                          const float* loc, const float* attn, const Dims& d, float* grad_value, float* grad_loc,
+                          float* grad_attn, hipStream_t stream);
 
 // msda_fwd_tiled.hip: LDS-tiled encoder forward (fp32, D = 32, Lq == S).
 bool tiled_forward_ok(const Dims& d);

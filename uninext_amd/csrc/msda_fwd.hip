@@ -161,7 +161,8 @@ msda_fwd_lanegroup(const float* __restrict__ value, const int64_t* __restrict__ 
     for (int s = 0; s < LP; ++s) gather(s);
   }
 
-  *reinterpret_cast<float4*>(out + pair * d.D + 4 * j) = acc;
+  const f32x4 accv = {acc.x, acc.y, acc.z, acc.w};
+  __builtin_nontemporal_store(accv, reinterpret_cast<f32x4*>(out + pair * d.D + 4 * j));
 }
 
 // ------------------------------------------------------------------------------------------------
