@@ -56,6 +56,7 @@ extern "C" {
 #define MSDA_ERR_BAD_DIMS (-2)      /* a dimension <= 0 (except batch/num_query == 0, which is a no-op) */
 #define MSDA_ERR_TOO_LARGE (-3)     /* a per-image extent does not fit the 32-bit offsets the kernels use */
 #define MSDA_ERR_BAD_VARIANT (-4)   /* MSDA_HIP_FWD_VARIANT / msda_hip_set_variant names an unknown kernel */
+#define MSDA_ERR_UNSUPPORTED (-5)   /* this entry point has no kernel for the given geometry: use the unfused one */
 
 int msda_hip_abi_version(void);
 const char* msda_hip_last_error(void);
@@ -85,6 +86,24 @@ int msda_hip_backward_f64(const double* grad_output, const double* value,
                           int spatial_size, int num_heads, int channels, int num_levels,
                           int num_query, int num_point, double* grad_value,
                           double* grad_sampling_loc, double* grad_attn_weight, void* stream);
+
+/*
+ * Forward with the elementwise prologue of MSDeformAttn.forward folded in
+ * (ops/modules/ms_deform_attn.py:99-112).  Instead of normalised sampling locations and
+ * softmaxed weights it takes the RAW Linear outputs and the reference points:
+ *   reference_points [batch, num_query, num_levels, ref_dim]   ref_dim 2: (x, y); 4: (cx, cy, w, h)
+ *   sampling_offsets [batch, num_query, num_heads * num_levels * num_point * 2]
+ *   attn_logits      [batch, num_query, num_heads * num_levels * num_point]
+ * and computes  attn = softmax over (levels x points);  loc = ref + off / (W_l, H_l)  (ref_dim 2)  or
+ * loc = ref_xy + off / num_point * ref_wh * 0.5  (ref_dim 4)  inside the kernel.  fp32, channels == 32,
+ * num_levels * num_point == 16 only: other geometries return MSDA_ERR_UNSUPPORTED and the caller uses
+ * msda_hip_forward_f32 after the PyTorch prologue.  Forward only (inference).
+ */
+int msda_hip_forward_fused_f32(const float* value, const int64_t* spatial_shapes,
+                               const int64_t* level_start_index, const float* reference_points, int ref_dim,
+                               const float* sampling_offsets, const float* attn_logits, int batch,
+                               int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                               int num_point, float* output, void* stream);
 
 /*
  * Kernel selection (tuning / A-B measurement only; results are identical up to fp32

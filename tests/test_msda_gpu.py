@@ -233,6 +233,33 @@ def test_tiled_forward_head_point_counts(M, L, P, variant, dev, api):
     assert torch.isfinite(out).all() and max_abs(_np(out), ref) < 1e-4
 
 
+@pytest.mark.parametrize("kind,flavour,levels", [
+    ("encoder", "model", ((40, 50), (20, 25), (10, 13), (5, 7))),          # S = 2665 < 4096: falls back
+    ("encoder", "uniform", ((64, 80), (32, 40), (16, 20), (8, 10))),       # last level 80 px: resident
+    ("encoder", "model", ((64, 80), (32, 40), (16, 20), (17, 17))),        # last level 289 px: too big, nothing resident
+    ("decoder", "model", ((64, 80), (32, 40), (16, 20), (8, 10))),         # Lq = 5000 arbitrary queries
+])
+def test_lgcl_forward_vs_oracle(kind, flavour, levels, dev, api):
+    """Lane-group kernel with the last pyramid level resident in LDS (any query set, any sampling pattern)."""
+    from oracle import msda_oracle
+    from uninext_amd import workloads
+    MSDA, lib = api
+    x = workloads.make_inputs(kind, flavour, batch=2, levels=levels, num_query=None if kind == "encoder" else 5000,
+                              seed=41, device=dev)
+    x["loc"][1, 7, 3, 3, 2, 0] = float("nan")
+    lib.set_variant("forward", "msda_fwd_lgcl")
+    try:
+        out = MSDA.ms_deform_attn_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], 64)
+    finally:
+        lib.set_variant("forward", "auto")
+    S = x["value"].shape[1]
+    assert lib.last_kernel("forward") == ("msda_fwd_lgcl" if x["loc"].shape[1] >= 4096 else "msda_fwd_lanegroup"), S
+    idx = torch.cat([torch.arange(0, 600), torch.arange(x["loc"].shape[1] - 600, x["loc"].shape[1])]).to(dev)
+    ref = msda_oracle.forward(x["value"], x["shapes"], x["lsi"], x["loc"][:, idx].contiguous(),
+                              x["attn"][:, idx].contiguous())
+    assert torch.isfinite(out).all() and max_abs(_np(out[:, idx]), ref) < 1e-4
+
+
 # ------------------------------------------------------------------------------------------------
 # full BASELINE sizes: oracle on a query subset + size-independent properties
 
@@ -243,15 +270,17 @@ def test_full_size_encoder_forward(flavour, dev, api):
     MSDA, lib = api
     x = workloads.make_inputs("encoder", flavour, batch=2, seed=3, device=dev)
     out = MSDA.ms_deform_attn_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], 64)
-    assert out.shape == (2, 22223, 256) and lib.last_kernel("forward") in ("msda_fwd_tiled", "msda_fwd_lanegroup")
-    other = "msda_fwd_lanegroup" if lib.last_kernel("forward") == "msda_fwd_tiled" else "msda_fwd_tiled"
-    lib.set_variant("forward", other)
-    try:
-        out_lg = MSDA.ms_deform_attn_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], 64)
-    finally:
-        lib.set_variant("forward", "auto")
-    assert lib.last_kernel("forward") == other
-    assert float((out - out_lg).abs().max()) < 2e-5  # two HIP kernels, different summation order only
+    assert out.shape == (2, 22223, 256)
+    auto_kernel = lib.last_kernel("forward")
+    assert auto_kernel in ("msda_fwd_lgcl", "msda_fwd_tiled", "msda_fwd_lanegroup")
+    for other in ("msda_fwd_lanegroup", "msda_fwd_tiled_l0", "msda_fwd_lgcl"):   # every fast kernel, full size
+        lib.set_variant("forward", other)
+        try:
+            out_o = MSDA.ms_deform_attn_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], 64)
+        finally:
+            lib.set_variant("forward", "auto")
+        assert lib.last_kernel("forward") == other.replace("_l0", "")
+        assert float((out - out_o).abs().max()) < 2e-5  # different HIP kernels: summation order only
     # (1) the oracle on a subset of queries (outputs of different queries are independent)
     idx = torch.cat([torch.arange(0, 300), torch.arange(16600, 16800), torch.arange(22000, 22223),
                      torch.randint(0, 22223, (500,), generator=torch.Generator().manual_seed(1))])
@@ -516,3 +545,92 @@ def test_module_forward_backward_vs_gridsample_port(ref_dim, dev, api):
     assert float((out - ref_out).abs().max()) < 1e-4
     for a, b in zip(grads, ref_grads):
         assert float((a - b).abs().max()) < 2e-4 * max(1.0, float(b.abs().max()))
+
+
+# ------------------------------------------------------------------------------------------------
+# fused prologue: softmax + sampling locations inside the kernel
+
+@pytest.mark.parametrize("ref_dim", [2, 4])
+def test_fused_forward_vs_oracle_and_unfused(ref_dim, dev, api):
+    import torch.nn.functional as F
+    from oracle import msda_oracle
+    from uninext_amd import ext, workloads
+    MSDA, lib = api
+    levels = ((25, 42), (13, 21), (7, 11), (4, 6))
+    S = sum(h * w for h, w in levels)
+    N, M, L, P = 2, 8, 4, 4
+    Lq = S if ref_dim == 2 else 300
+    g = torch.Generator().manual_seed(50 + ref_dim)
+    value = torch.randn(N, S, M, 32, generator=g).to(dev)
+    offsets = (torch.randn(N, Lq, M * L * P * 2, generator=g) * 2.5).to(dev)
+    logits = (torch.randn(N, Lq, M * L * P, generator=g) * 3.0).to(dev)
+    logits[0, 1, :16] = 80.0   # equal large logits: softmax must not overflow
+    if ref_dim == 2:
+        ref = workloads.encoder_reference_points(levels, dev)[None, :, None, :].expand(N, S, L, 2).contiguous()
+    else:
+        ref = torch.rand(N, Lq, L, 4, generator=g).to(dev)
+        ref[..., 2:] = ref[..., 2:] * 0.4 + 0.02
+    sh, lsi = workloads.level_tensors(levels, dev)
+    assert ext.fused_forward_supported(value, ref, L, P)
+    out = ext.ms_deform_attn_forward_fused(value, sh, lsi, ref, offsets, logits, P)
+    assert lib.last_kernel("forward") == "msda_fwd_fused"
+    # the reference's prologue (ops/modules/ms_deform_attn.py:99-112) in torch, then the C oracle
+    off = offsets.view(N, Lq, M, L, P, 2)
+    attn = F.softmax(logits.view(N, Lq, M, L * P), -1).view(N, Lq, M, L, P)
+    if ref_dim == 2:
+        wh = torch.stack([sh[..., 1], sh[..., 0]], -1)
+        loc = ref[:, :, None, :, None, :] + off / wh[None, None, None, :, None, :]
+    else:
+        loc = ref[:, :, None, :, None, :2] + off / P * ref[:, :, None, :, None, 2:] * 0.5
+    oracle_out = msda_oracle.forward(value, sh, lsi, loc.contiguous(), attn.contiguous())
+    assert max_abs(_np(out), oracle_out) < 1e-4
+    unfused = MSDA.ms_deform_attn_forward(value, sh, lsi, loc.contiguous(), attn.contiguous(), 64)
+    assert float((out - unfused).abs().max()) < 2e-5
+
+
+def test_fused_forward_rejects_unsupported_geometry(dev, api):
+    from uninext_amd import ext, workloads
+    levels = ((6, 5), (3, 3))
+    sh, lsi = workloads.level_tensors(levels, dev)
+    value = torch.randn(1, 39, 2, 16, device=dev)            # 16 channels per head: no fused kernel
+    ref = torch.rand(1, 5, 2, 2, device=dev)
+    assert not ext.fused_forward_supported(value, ref, 2, 8)
+    with pytest.raises(RuntimeError, match="fused forward needs"):
+        ext.ms_deform_attn_forward_fused(value, sh, lsi, ref, torch.zeros(1, 5, 2 * 2 * 8 * 2, device=dev),
+                                         torch.zeros(1, 5, 2 * 2 * 8, device=dev), 8)
+
+
+@pytest.mark.parametrize("ref_dim", [2, 4])
+def test_module_inference_uses_fused_kernel_and_matches_autograd_path(ref_dim, dev, api):
+    from uninext_amd.modules import MSDeformAttn
+    from uninext_amd.workloads import level_tensors
+    _, lib = api
+    torch.manual_seed(12)
+    levels = ((10, 13), (5, 7), (3, 4), (2, 2))
+    S = sum(h * w for h, w in levels)
+    N, Lq = 2, 31
+    layer = MSDeformAttn(256, 4, 8, 4).to(dev).eval()
+    with torch.no_grad():
+        layer.sampling_offsets.weight.normal_(0, 0.02)
+        layer.attention_weights.weight.normal_(0, 0.1)
+    query, src = torch.randn(N, Lq, 256, device=dev), torch.randn(N, S, 256, device=dev)
+    ref = torch.rand(N, Lq, 4, ref_dim, device=dev)
+    mask = torch.zeros(N, S, dtype=torch.bool, device=dev)
+    mask[0, :9] = True
+    sh, lsi = level_tensors(levels, dev)
+    with torch.no_grad():
+        fused = layer(query, ref, src, sh, lsi, mask)
+        assert lib.last_kernel("forward") == "msda_fwd_fused"
+        MSDeformAttn.fuse_prologue = False
+        try:
+            plain = layer(query, ref, src, sh, lsi, mask)
+        finally:
+            MSDeformAttn.fuse_prologue = True
+        assert lib.last_kernel("forward") != "msda_fwd_fused"
+    assert float((fused - plain).abs().max()) < 2e-5
+    # with gradients required the module must take the differentiable path
+    q2 = query.clone().requires_grad_(True)
+    out = layer(q2, ref, src, sh, lsi, mask)
+    assert lib.last_kernel("forward") != "msda_fwd_fused"
+    out.sum().backward()
+    assert q2.grad is not None and torch.isfinite(q2.grad).all()

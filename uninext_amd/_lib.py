@@ -10,6 +10,7 @@ ABI_VERSION = 1
 EXPORTS = (
     "msda_hip_abi_version", "msda_hip_last_error",
     "msda_hip_forward_f32", "msda_hip_forward_f64", "msda_hip_backward_f32", "msda_hip_backward_f64",
+    "msda_hip_forward_fused_f32",
     "msda_hip_set_variant", "msda_hip_get_variant", "msda_hip_variant_name", "msda_hip_last_kernel",
 )
 
@@ -35,6 +36,8 @@ def load():
         f.argtypes, f.restype = [p, p, p, p, p, i, i, i, i, i, i, i, p, p], i
         g = getattr(lib, "msda_hip_backward_" + suf)
         g.argtypes, g.restype = [p, p, p, p, p, p, i, i, i, i, i, i, i, p, p, p, p], i
+    lib.msda_hip_forward_fused_f32.argtypes = [p, p, p, p, i, p, p, i, i, i, i, i, i, i, p, p]
+    lib.msda_hip_forward_fused_f32.restype = i
     lib.msda_hip_set_variant.argtypes, lib.msda_hip_set_variant.restype = [i, i], i
     lib.msda_hip_get_variant.argtypes, lib.msda_hip_get_variant.restype = [i], i
     lib.msda_hip_variant_name.argtypes, lib.msda_hip_variant_name.restype = [i, i], s

@@ -55,7 +55,10 @@ struct BwdMeta {
   uint32_t slot_tab[kBSlots];                     // (level << 28) | (row * W_level + col)
 };
 
-constexpr int kBWinBytes = (kBSlots + 8) * 128;   // last 8 slots: per-pair sinks for dead corners / far samples
+// Accumulator slots are 33 words apart: with 32-word slots every pair's lane j would hit bank 4j + c whatever
+// the pixel (8-way conflicts, measured 64 % of the LDS cycles); with 33 the pixel index rotates the banks.
+constexpr int kBSlotBytes = 132;
+constexpr int kBWinBytes = ((kBSlots + 8) * kBSlotBytes + 15) / 16 * 16;   // + 8 per-pair sink slots
 constexpr int kBLdsBytes = kBWinBytes + kBRecBytes + ((sizeof(BwdMeta) + 15) / 16) * 16;
 static_assert(kBLdsBytes <= 160 * 1024, "one workgroup per CU");
 
@@ -156,7 +159,7 @@ msda_bwd_tiled(const float* __restrict__ grad_out, const float* __restrict__ val
   // ---- per-lane constants ----------------------------------------------------------------------------
   const int pw = lane >> 3, j = lane & 7;            // pair of the wave, lane of the pair
   const uint32_t lane_off = (uint32_t)j * 16u;
-  const uint32_t sink = smem_base + (kBSlots + pw) * 128;      // this pair's sink slot (never flushed)
+  const uint32_t sink = smem_base + (kBSlots + pw) * kBSlotBytes;   // this pair's sink slot (never flushed)
   const uint32_t rec_pair = kBWinBytes + wv * kBWaveRec + pw * kBPairRec;
   // per-level launch constants used by the compile-time-unrolled sample steps: force them into SGPRs
   int lvH[kBMaxL], lvW[kBMaxL];
@@ -168,7 +171,7 @@ msda_bwd_tiled(const float* __restrict__ grad_out, const float* __restrict__ val
     lvH[l] = __builtin_amdgcn_readfirstlane(mt.H[ll]);
     lvW[l] = __builtin_amdgcn_readfirstlane(mt.W[ll]);
     lvRowG[l] = (uint32_t)lvW[l] * pix_bytes;
-    lvRowL[l] = (uint32_t)__builtin_amdgcn_readfirstlane(mt.WW[ll]) * 128u;
+    lvRowL[l] = (uint32_t)__builtin_amdgcn_readfirstlane(mt.WW[ll]) * (uint32_t)kBSlotBytes;
   }
   const int TY = mt.TY, TX = mt.TX;
   const int items = d.N * M * TY * TX;
@@ -209,7 +212,7 @@ msda_bwd_tiled(const float* __restrict__ grad_out, const float* __restrict__ val
     }
     if (tid == 0) { mt.gmax_bits = 0u; mt.amax_bits = 0u; }
     // zero the accumulator windows (and the sink)
-    for (int o = tid * 16; o < (nslots + 0) * 128; o += kBT * 16) *reinterpret_cast<f32x4*>(smem + o) = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int o = tid * 16; o < nslots * kBSlotBytes; o += kBT * 16) *reinterpret_cast<f32x4*>(smem + o) = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
     int cum[kBMaxL + 1];
     cum[0] = 0;
@@ -335,7 +338,7 @@ msda_bwd_tiled(const float* __restrict__ grad_out, const float* __restrict__ val
               if (!(rows_in && cols_in) || !use_lds) flags |= 16u;   // far: straight to global memory
               r0[0] = x - xf; r0[1] = y - yf; r0[2] = at[ps];
               g00 = (uint32_t)(St + y0 * Wl + x0) * pix_bytes;
-              l00 = smem_base + (uint32_t)(Sl + ry * Ww + cx) * 128u;
+              l00 = smem_base + (uint32_t)(Sl + ry * Ww + cx) * (uint32_t)kBSlotBytes;
               if (Ww > 0) {   // statistics for the next tile's window placement
                 const float dx = x - mt.gcx[lq], dy = y - mt.gcy[lq];
                 if (fabsf(dx) <= 12.f && fabsf(dy) <= 12.f) { dsum_x[ps] += dx; dsum_y[ps] += dy; dsum_n[ps] += 1.f; }
@@ -393,9 +396,9 @@ msda_bwd_tiled(const float* __restrict__ grad_out, const float* __restrict__ val
             // near samples: accumulate into the LDS window; dead corners and far samples go to the pair's sink slot
             const bool near = (flags & 16u) == 0u;
             const uint32_t a1 = ((flags & 1u) && near ? cur.r1.y : sink) + lane_off;
-            const uint32_t a2 = ((flags & 2u) && near ? cur.r1.y + 128u : sink) + lane_off;
+            const uint32_t a2 = ((flags & 2u) && near ? cur.r1.y + (uint32_t)kBSlotBytes : sink) + lane_off;
             const uint32_t a3 = ((flags & 4u) && near ? cur.r1.y + lvRowL[l] : sink) + lane_off;
-            const uint32_t a4 = ((flags & 8u) && near ? cur.r1.y + lvRowL[l] + 128u : sink) + lane_off;
+            const uint32_t a4 = ((flags & 8u) && near ? cur.r1.y + lvRowL[l] + (uint32_t)kBSlotBytes : sink) + lane_off;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
               lds_add(a1 + 4u * c, cvt_rn_i32(w1 * tgs[c]));
@@ -470,7 +473,7 @@ msda_bwd_tiled(const float* __restrict__ grad_out, const float* __restrict__ val
       const int ch = tid & 31;
       const int b0 = mt.base[0], b1 = mt.base[1], b2 = mt.base[2], b3 = mt.base[3];
       for (int p = tid >> 5; p < nslots; p += kBT / 32) {
-        const float v = (float)*reinterpret_cast<const int*>(smem + p * 128 + ch * 4) * inv_scale;
+        const float v = (float)*reinterpret_cast<const int*>(smem + p * kBSlotBytes + ch * 4) * inv_scale;
         const uint32_t e = mt.slot_tab[p];
         const uint32_t l = e >> 28;
         const int base = l == 0 ? b0 : (l == 1 ? b1 : (l == 2 ? b2 : b3));

@@ -18,8 +18,8 @@ std::atomic<const char*> g_last_kernel[2] = {{""}, {""}};
 std::atomic<int> g_variant[2] = {{-1}, {-1}};  // -1: not initialised (read env once)
 
 const char* const kVariantNames[2][msda::kNumVariants] = {
-    {"auto", "msda_fwd_generic", "msda_fwd_lanegroup", "msda_fwd_tiled", "msda_fwd_tiled_l0", "msda_fwd_tiled_l0big"},
-    {"auto", "msda_bwd_generic", "msda_bwd_lanegroup", "msda_bwd_tiled", "msda_bwd_tiled", "msda_bwd_tiled"},
+    {"auto", "msda_fwd_generic", "msda_fwd_lanegroup", "msda_fwd_tiled", "msda_fwd_tiled_l0", "msda_fwd_tiled_l0big", "msda_fwd_lgcl"},
+    {"auto", "msda_bwd_generic", "msda_bwd_lanegroup", "msda_bwd_tiled", "msda_bwd_tiled", "msda_bwd_tiled", "msda_bwd_tiled"},
 };
 
 int current_variant(int which) {
@@ -122,6 +122,23 @@ int msda_hip_backward_f64(const double* grad_output, const double* value, const 
   const msda::Dims d{batch, spatial_size, num_heads, channels, num_levels, num_query, num_point};
   return backward_impl<double>(grad_output, value, spatial_shapes, level_start_index, sampling_loc, attn_weight, d,
                                grad_value, grad_sampling_loc, grad_attn_weight, stream);
+}
+
+int msda_hip_forward_fused_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                               const float* reference_points, int ref_dim, const float* sampling_offsets,
+                               const float* attn_logits, int batch, int spatial_size, int num_heads, int channels,
+                               int num_levels, int num_query, int num_point, float* output, void* stream) {
+  const msda::Dims d{batch, spatial_size, num_heads, channels, num_levels, num_query, num_point};
+  if (int rc = check_dims(d)) return rc;
+  if (!msda::fused_forward_ok(d, ref_dim))
+    return fail(MSDA_ERR_UNSUPPORTED, "fused forward needs channels == 32, num_levels * num_point == 16, ref_dim 2 or 4");
+  if (d.N == 0 || d.Lq == 0) return 0;
+  if (!value || !spatial_shapes || !level_start_index || !reference_points || !sampling_offsets || !attn_logits || !output)
+    return fail(MSDA_ERR_NULL_POINTER, "null pointer argument");
+  const int rc = msda::launch_forward_fused(value, spatial_shapes, level_start_index, reference_points, ref_dim,
+                                            sampling_offsets, attn_logits, d, output, (hipStream_t)stream);
+  g_last_kernel[0].store("msda_fwd_fused", std::memory_order_relaxed);
+  return finish(rc, "msda_hip_forward_fused");
 }
 
 int msda_hip_set_variant(int which, int variant) {

@@ -81,7 +81,14 @@ int launch_backward(int variant, const T* grad_out, const T* value, const int64_
                     hipStream_t stream, const char** kernel_name);
 
 // Variant numbering shared with include/msda_hip.h.
-enum Variant { kAuto = 0, kGeneric = 1, kLaneGroup = 2, kTiled = 3, kTiledL0 = 4, kTiledL0Big = 5, kNumVariants = 6 };
+enum Variant { kAuto = 0, kGeneric = 1, kLaneGroup = 2, kTiled = 3, kTiledL0 = 4, kTiledL0Big = 5, kLaneGroupCL = 6,
+               kNumVariants = 7 };
+
+// msda_fwd.hip: forward with the MSDeformAttn prologue (softmax + sampling locations) fused in.
+bool fused_forward_ok(const Dims& d, int ref_dim);
+int launch_forward_fused(const float* value, const int64_t* shapes, const int64_t* lsi, const float* ref_points,
+                         int ref_dim, const float* offsets, const float* logits, const Dims& d, float* out,
+                         hipStream_t stream);
 
 // msda_bwd_tiled.hip: backward with grad_value privatised in LDS (fp32, D = 32, P = 4, Lq == S).
 bool tiled_backward_ok(const Dims& d);

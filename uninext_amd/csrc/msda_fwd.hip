@@ -17,6 +17,8 @@
 //                            without touching memory.  Workgroups are ordered head-minor so that
 //                            (observed, not required) XCD x only ever touches head x's 1/8 slice of
 //                            `value` (2.8 MB / image at the R50 shapes, inside its 4 MiB L2).
+#include <type_traits>
+
 #include "msda_common.hpp"
 
 namespace msda {
@@ -166,6 +168,319 @@ msda_fwd_lanegroup(const float* __restrict__ value, const int64_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// msda_fwd_fused: msda_fwd_lanegroup<8,16> with MSDeformAttn.forward's elementwise prologue folded in
+// (ops/modules/ms_deform_attn.py:99-112): the kernel reads the RAW outputs of the sampling_offsets and
+// attention_weights Linear layers plus the reference points and computes, in the lanes that prepare the samples,
+//     attn = softmax over the 16 (level, point) logits of the (query, head) pair       (:100-101)
+//     loc  = ref_xy + offset / (W_l, H_l)                         (2-d reference points, :103-106)
+//     loc  = ref_xy + offset / P * ref_wh * 0.5                   (4-d reference boxes,  :107-109)
+// The softmax runs across the 8 lanes of the pair with DPP (2 logits per lane).  This removes the separate
+// softmax and location kernels and the write + re-read of the 45.5 MB `sampling_locations` tensor per encoder
+// call.  Inference path only: no gradients flow through this entry point.
+template <int CTRL>
+__device__ __forceinline__ float fdpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float group8_max(float v) {
+  v = fmaxf(v, fdpp<0xB1>(v));
+  v = fmaxf(v, fdpp<0x4E>(v));
+  v = fmaxf(v, fdpp<0x141>(v));
+  return v;
+}
+__device__ __forceinline__ float group8_add(float v) {
+  v += fdpp<0xB1>(v);
+  v += fdpp<0x4E>(v);
+  v += fdpp<0x141>(v);
+  return v;
+}
+
+template <int REFD>   // 2 or 4
+__global__ void __launch_bounds__(kBlock, 4)
+msda_fwd_fused(const float* __restrict__ value, const int64_t* __restrict__ shapes,
+               const int64_t* __restrict__ lsi, const float* __restrict__ ref_points,
+               const float* __restrict__ offsets, const float* __restrict__ logits, Dims d,
+               float* __restrict__ out) {
+  constexpr int G = 8, LPT = 16, kPairs = kBlock / G;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* smp_H = reinterpret_cast<int*>(smem);
+  int* smp_W = smp_H + kMaxLP;
+  int* smp_start = smp_W + kMaxLP;
+  char* rec_base = smem + kLevelTableBytes;
+  const int tid = threadIdx.x;
+  if (tid < LPT) {
+    const int l = tid / d.P;
+    smp_H[tid] = (int)shapes[2 * l];
+    smp_W[tid] = (int)shapes[2 * l + 1];
+    smp_start[tid] = (int)lsi[l];
+  }
+  __syncthreads();
+
+  const int b = blockIdx.y;
+  const int m = blockIdx.x % d.M;
+  const int g = tid / G, j = tid % G;
+  const int q = (blockIdx.x / d.M) * kPairs + g;
+  if (q >= d.Lq) return;   // whole lane-groups drop out; softmax and exchange are group-local
+
+  const int64_t pair = ((int64_t)b * d.Lq + q) * d.M + m;
+  const uint32_t pix_bytes = (uint32_t)d.M * 128u;
+  char* rec = rec_base + g * (LPT * 32 + 16);
+
+  // raw Linear outputs of this lane's two samples (2j, 2j+1), their level and its reference point
+  const float4 off = *reinterpret_cast<const float4*>(offsets + pair * (2 * LPT) + 4 * j);
+  const float2 lg = *reinterpret_cast<const float2*>(logits + pair * LPT + 2 * j);
+  const int s0 = 2 * j;
+  const int lvl = s0 / d.P;                                       // both samples share it when P is even
+  const int lvl1 = (s0 + 1) / d.P;
+  const float* rp = ref_points + ((int64_t)b * d.Lq + q) * d.L * REFD;
+  // softmax over the pair's 16 logits
+  const float mx = group8_max(fmaxf(lg.x, lg.y));
+  const float e0 = __expf(lg.x - mx), e1 = __expf(lg.y - mx);
+  const float inv = 1.0f / group8_add(e0 + e1);
+  const float a0 = e0 * inv, a1 = e1 * inv;
+
+  auto location = [&](int level, float ox, float oy, float& lx, float& ly) {
+    if constexpr (REFD == 2) {
+      const float2 r = *reinterpret_cast<const float2*>(rp + level * 2);
+      lx = r.x + ox / (float)smp_W[level * d.P];
+      ly = r.y + oy / (float)smp_H[level * d.P];
+    } else {
+      const float4 r = *reinterpret_cast<const float4*>(rp + level * 4);
+      lx = r.x + ox / (float)d.P * r.z * 0.5f;
+      ly = r.y + oy / (float)d.P * r.w * 0.5f;
+    }
+  };
+
+  auto prepare = [&](int s, float lx, float ly, float a) {
+    const int H = smp_H[s], W = smp_W[s];
+    const Sample<float> sm = make_sample<float>(lx, ly, H, W);
+    const float wa = sm.hh * a, wb = sm.lh * a;
+    float4 w;
+    w.x = sm.ok1 ? wa * sm.hw : 0.f;
+    w.y = sm.ok2 ? wa * sm.lw : 0.f;
+    w.z = sm.ok3 ? wb * sm.hw : 0.f;
+    w.w = sm.ok4 ? wb * sm.lw : 0.f;
+    const uint32_t o1 = (uint32_t)(smp_start[s] + sm.h_low * W + sm.w_low) * pix_bytes;
+    u32x4 o;
+    o[0] = sm.ok1 ? o1 : kOobOffset;
+    o[1] = sm.ok2 ? o1 + pix_bytes : kOobOffset;
+    o[2] = sm.ok3 ? o1 + (uint32_t)W * pix_bytes : kOobOffset;
+    o[3] = sm.ok4 ? o1 + (uint32_t)(W + 1) * pix_bytes : kOobOffset;
+    *reinterpret_cast<float4*>(rec + s * 32) = w;
+    *reinterpret_cast<u32x4*>(rec + s * 32 + 16) = o;
+  };
+  float lx, ly;
+  location(lvl, off.x, off.y, lx, ly);
+  prepare(s0, lx, ly, a0);
+  location(lvl1, off.z, off.w, lx, ly);
+  prepare(s0 + 1, lx, ly, a1);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(value) + (int64_t)b * d.S * d.M * 32, 0, (int)((uint32_t)d.S * pix_bytes), 0x00020000);
+  const uint32_t head_off = (uint32_t)m * 128u, lane_off = (uint32_t)j * 16u;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < LPT; ++s) {
+    const float4 w = *reinterpret_cast<const float4*>(rec + s * 32);
+    const u32x4 o = *reinterpret_cast<const u32x4*>(rec + s * 32 + 16);
+    const f32x4 r1 = buffer_load_f32x4(rsrc, o[0] + lane_off, head_off);
+    const f32x4 r2 = buffer_load_f32x4(rsrc, o[1] + lane_off, head_off);
+    const f32x4 r3 = buffer_load_f32x4(rsrc, o[2] + lane_off, head_off);
+    const f32x4 r4 = buffer_load_f32x4(rsrc, o[3] + lane_off, head_off);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      acc[c] = fmaf(w.w, r4[c], fmaf(w.z, r3[c], fmaf(w.y, r2[c], fmaf(w.x, r1[c], acc[c]))));
+  }
+  __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(out + pair * 32 + 4 * j));
+}
+
+bool fused_forward_ok(const Dims& d, int ref_dim) {
+  return d.D == 32 && d.L * d.P == 16 && d.P % 2 == 0 && (ref_dim == 2 || ref_dim == 4) &&
+         (int64_t)d.S * d.M * 128 < (int64_t)kOobOffset && d.N <= 65535;
+}
+
+int launch_forward_fused(const float* value, const int64_t* shapes, const int64_t* lsi, const float* ref_points,
+                         int ref_dim, const float* offsets, const float* logits, const Dims& d, float* out,
+                         hipStream_t stream) {
+  constexpr int kPairs = kBlock / 8;
+  const size_t lds = kLevelTableBytes + (size_t)kPairs * (16 * 32 + 16);
+  dim3 grid((unsigned)(d.M * ((d.Lq + kPairs - 1) / kPairs)), (unsigned)d.N);
+  if (ref_dim == 2)
+    hipLaunchKernelGGL(msda_fwd_fused<2>, grid, dim3(kBlock), lds, stream, value, shapes, lsi, ref_points, offsets, logits,
+                       d, out);
+  else
+    hipLaunchKernelGGL(msda_fwd_fused<4>, grid, dim3(kBlock), lds, stream, value, shapes, lsi, ref_points, offsets, logits,
+                       d, out);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// msda_fwd_lgcl: the lane-group kernel with the COARSEST level(s) of head m resident in LDS.
+//
+// rocprof (profiles/) shows msda_fwd_lanegroup bound by the vector-L1 / TA rate: 40 M 64-byte
+// accesses per encoder call at one per clock per CU.  The trailing pyramid levels are tiny (level 3 of the R50
+// pyramid: 273 pixels = 35 KB per head) yet receive a quarter of all samples -- so a persistent workgroup copies
+// them into LDS once and serves those samples with ds_read_b128 for ANY sampling pattern (no tiles, no
+// heuristics), which takes 25 % of the load off the L1 path while the LDS pipe is otherwise idle.
+// fp32, D = 32, L*P = 16 with P = 4.  Workgroup (m, k) of image b walks the query chunks k, k + K, ...
+constexpr int kClSlots = 280;                                   // resident pixels (35 KB) + one all-zero slot
+constexpr int kClLdsBytes = kLevelTableBytes + (kClSlots + 1) * 128 + (kBlock / 8) * (16 * 32 + 16);
+
+__global__ void __launch_bounds__(kBlock, 3)
+msda_fwd_lgcl(const float* __restrict__ value, const int64_t* __restrict__ shapes,
+              const int64_t* __restrict__ lsi, const float* __restrict__ loc,
+              const float* __restrict__ attn, Dims d, float* __restrict__ out) {
+  constexpr int G = 8, LPT = 16, P = 4, kPairs = kBlock / G;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* smp_H = reinterpret_cast<int*>(smem);
+  int* smp_W = smp_H + kMaxLP;
+  int* smp_start = smp_W + kMaxLP;
+  char* cl_base = smem + kLevelTableBytes;                       // resident pixels, 128 B each
+  char* rec_base = cl_base + (kClSlots + 1) * 128;
+  const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+  const int tid = threadIdx.x;
+  if (tid < LPT) {
+    const int l = tid / P;
+    smp_H[tid] = (int)shapes[2 * l];
+    smp_W[tid] = (int)shapes[2 * l + 1];
+    smp_start[tid] = (int)lsi[l];
+  }
+  __syncthreads();
+  // resident set = the last level, if it has at most kClSlots pixels (more levels would fit for small pyramids,
+  // but every extra specialisation of the gather loop costs registers for all of them)
+  int res_l = LPT / P, res_pix0 = d.S;
+  {
+    const int st = smp_start[LPT - 1];
+    if (d.S - st <= kClSlots) { res_l = LPT / P - 1; res_pix0 = st; }
+  }
+  res_l = __builtin_amdgcn_readfirstlane(res_l);
+  res_pix0 = __builtin_amdgcn_readfirstlane(res_pix0);
+  const int nres = d.S - res_pix0;
+
+  const int b = blockIdx.y;
+  const int m = blockIdx.x % d.M;
+  const int k0 = blockIdx.x / d.M, K = gridDim.x / d.M;
+  const uint32_t pix_bytes = (uint32_t)d.M * 128u;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(value) + (int64_t)b * d.S * d.M * 32, 0, (int)((uint32_t)d.S * pix_bytes), 0x00020000);
+  const uint32_t head_off = (uint32_t)m * 128u;
+
+  // ---- copy the resident levels of (b, m) into LDS; slot `nres` stays zero for dead corners -----------
+  for (int i = tid >> 3; i <= nres; i += kBlock / 8) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (i < nres) v = buffer_load_f32x4(rsrc, (uint32_t)(res_pix0 + i) * pix_bytes + (uint32_t)(tid & 7) * 16u, head_off);
+    *reinterpret_cast<f32x4*>(cl_base + i * 128 + (tid & 7) * 16) = v;
+  }
+  __syncthreads();
+
+  const int g = tid / G, j = tid % G;
+  char* rec = rec_base + g * (LPT * 32 + 16);
+  const uint32_t lane_off = (uint32_t)j * 16u;
+  const uint32_t cl_addr0 = smem_base + kLevelTableBytes;        // LDS byte address of resident pixel 0
+  const uint32_t zero_slot = cl_addr0 + (uint32_t)nres * 128u;
+  const int nchunks = (d.Lq + kPairs - 1) / kPairs;
+
+  // The resident level count is only known on the device; branch ONCE into a loop specialised for it so that
+  // every gather step is either pure-LDS or pure-buffer at compile time (a per-step runtime branch makes the
+  // scheduler keep both paths' registers alive: 168 VGPRs + spills instead of ~70).
+  auto run = [&](auto res_tag) {
+    constexpr int RES_L = decltype(res_tag)::value;
+    for (int chunk = k0; chunk < nchunks; chunk += K) {
+      const int q = chunk * kPairs + g;
+      const bool live = q < d.Lq;
+      const int64_t pair = ((int64_t)b * d.Lq + (live ? q : 0)) * d.M + m;
+
+      auto prepare = [&](int s, float lx, float ly, float a) {
+        const int H = smp_H[s], W = smp_W[s];
+        const Sample<float> sm = make_sample<float>(lx, ly, H, W);
+        const float wa = sm.hh * a, wb = sm.lh * a;
+        float4 w;
+        w.x = (live && sm.ok1) ? wa * sm.hw : 0.f;
+        w.y = (live && sm.ok2) ? wa * sm.lw : 0.f;
+        w.z = (live && sm.ok3) ? wb * sm.hw : 0.f;
+        w.w = (live && sm.ok4) ? wb * sm.lw : 0.f;
+        const int pix1 = smp_start[s] + sm.h_low * W + sm.w_low;
+        u32x4 o;
+        if (s / P >= RES_L) {   // this sample's level lives in LDS
+          const uint32_t a1 = cl_addr0 + (uint32_t)(pix1 - res_pix0) * 128u;
+          o[0] = sm.ok1 ? a1 : zero_slot;
+          o[1] = sm.ok2 ? a1 + 128u : zero_slot;
+          o[2] = sm.ok3 ? a1 + (uint32_t)W * 128u : zero_slot;
+          o[3] = sm.ok4 ? a1 + (uint32_t)(W + 1) * 128u : zero_slot;
+        } else {
+          const uint32_t o1 = (uint32_t)pix1 * pix_bytes;
+          o[0] = sm.ok1 ? o1 : kOobOffset;
+          o[1] = sm.ok2 ? o1 + pix_bytes : kOobOffset;
+          o[2] = sm.ok3 ? o1 + (uint32_t)W * pix_bytes : kOobOffset;
+          o[3] = sm.ok4 ? o1 + (uint32_t)(W + 1) * pix_bytes : kOobOffset;
+        }
+        *reinterpret_cast<float4*>(rec + s * 32) = w;
+        *reinterpret_cast<u32x4*>(rec + s * 32 + 16) = o;
+      };
+      {
+        float4 lc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float2 at = make_float2(0.f, 0.f);
+        if (live) {
+          lc = *reinterpret_cast<const float4*>(loc + pair * (2 * LPT) + 4 * j);
+          at = *reinterpret_cast<const float2*>(attn + pair * LPT + 2 * j);
+        }
+        prepare(2 * j, lc.x, lc.y, at.x);
+        prepare(2 * j + 1, lc.z, lc.w, at.y);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  #pragma unroll
+      for (int s = 0; s < LPT; ++s) {
+        const float4 w = *reinterpret_cast<const float4*>(rec + s * 32);
+        const u32x4 o = *reinterpret_cast<const u32x4*>(rec + s * 32 + 16);
+        f32x4 r1, r2, r3, r4;
+        if (s / P >= RES_L) {   // compile-time after unrolling
+          r1 = *reinterpret_cast<const f32x4 __attribute__((address_space(3)))*>((uintptr_t)(o[0] + lane_off));
+          r2 = *reinterpret_cast<const f32x4 __attribute__((address_space(3)))*>((uintptr_t)(o[1] + lane_off));
+          r3 = *reinterpret_cast<const f32x4 __attribute__((address_space(3)))*>((uintptr_t)(o[2] + lane_off));
+          r4 = *reinterpret_cast<const f32x4 __attribute__((address_space(3)))*>((uintptr_t)(o[3] + lane_off));
+        } else {
+          r1 = buffer_load_f32x4(rsrc, o[0] + lane_off, head_off);
+          r2 = buffer_load_f32x4(rsrc, o[1] + lane_off, head_off);
+          r3 = buffer_load_f32x4(rsrc, o[2] + lane_off, head_off);
+          r4 = buffer_load_f32x4(rsrc, o[3] + lane_off, head_off);
+        }
+  #pragma unroll
+        for (int c = 0; c < 4; ++c)
+          acc[c] = fmaf(w.w, r4[c], fmaf(w.z, r3[c], fmaf(w.y, r2[c], fmaf(w.x, r1[c], acc[c]))));
+      }
+      if (live) __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(out + pair * 32 + 4 * j));
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();   // the next chunk rewrites the records
+    }
+
+  };
+  if (res_l == LPT / P - 1) run(std::integral_constant<int, LPT / P - 1>{});
+  else run(std::integral_constant<int, LPT / P>{});
+}
+
+static inline bool lgcl_ok(const Dims& d) {
+  return d.D == 32 && d.P == 4 && d.L == 4 && (int64_t)d.S * d.M * 128 < (int64_t)kOobOffset && d.N <= 65535 &&
+         d.Lq >= 4096;   // the resident copy is amortised over >= 2 query chunks per workgroup
+}
+
+static int launch_lgcl(const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc,
+                       const float* attn, const Dims& d, float* out, hipStream_t stream) {
+  const int nchunks = (d.Lq + 31) / 32;
+  int K = 768 / (d.M * d.N);   // ~3 resident workgroups per CU
+  K = K < 1 ? 1 : (K > nchunks ? nchunks : K);
+  hipLaunchKernelGGL(msda_fwd_lgcl, dim3((unsigned)(d.M * K), (unsigned)d.N), dim3(kBlock), kClLdsBytes, stream, value,
+                     shapes, lsi, loc, attn, d, out);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 static inline bool lanegroup_ok(const Dims& d, int* G_out) {
   if (d.D % 4 != 0) return false;
   const int G = d.D / 4;
@@ -200,6 +515,11 @@ int launch_forward<float>(int variant, const float* value, const int64_t* shapes
   const bool tl = tiled_forward_ok(d);
   // the tiled kernel is selected automatically only once it beats the lane-group kernel (kbench A/B)
   if (variant == kAuto) variant = (kTiledIsDefault && tl && d.S >= 4096) ? kTiled : (lg ? kLaneGroup : kGeneric);
+  if (variant == kLaneGroupCL && !lgcl_ok(d)) variant = kLaneGroup;
+  if (variant == kLaneGroupCL) {
+    *kernel_name = "msda_fwd_lgcl";
+    return launch_lgcl(value, shapes, lsi, loc, attn, d, out, stream);
+  }
   if (variant >= kTiled && !tl) variant = lg ? kLaneGroup : kGeneric;
   if (variant == kLaneGroup && !lg) variant = kGeneric;
   if (variant >= kTiled) {

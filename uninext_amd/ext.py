@@ -92,3 +92,40 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     if rc != 0:
         _raise(rc)
     return [grad_value, grad_loc, grad_attn]
+
+
+ERR_UNSUPPORTED = -5   # MSDA_ERR_UNSUPPORTED in include/msda_hip.h
+
+
+def fused_forward_supported(value, reference_points, num_levels, num_points):
+    """Geometry the fused-prologue kernel covers (include/msda_hip.h): fp32 on the GPU, 32 channels per head,
+    levels * points == 16, 2-d or 4-d reference points."""
+    return (value.is_cuda and value.dtype == torch.float32 and value.dim() == 4 and value.shape[3] == 32
+            and num_levels * num_points == 16 and num_points % 2 == 0 and reference_points.shape[-1] in (2, 4))
+
+
+def ms_deform_attn_forward_fused(value, spatial_shapes, level_start_index, reference_points, sampling_offsets,
+                                 attention_logits, num_points):
+    """MSDeformAttn.forward's softmax + sampling-location arithmetic + sampling in ONE kernel
+    (ops/modules/ms_deform_attn.py:99-113).  `sampling_offsets` [N, Lq, M*L*P*2] and `attention_logits`
+    [N, Lq, M*L*P] are the raw Linear outputs, `reference_points` [N, Lq, L, 2|4].  Inference only (no autograd).
+    Raises RuntimeError for unsupported geometry -- check fused_forward_supported() first."""
+    lib, _ = _prep(value, spatial_shapes, level_start_index, sampling_offsets, attention_logits,
+                   extra=(("reference_points", reference_points),))
+    N, S, M, D = value.shape
+    L = spatial_shapes.shape[0]
+    Lq = sampling_offsets.shape[1]
+    P = int(num_points)
+    if sampling_offsets.shape != (N, Lq, M * L * P * 2) or attention_logits.shape != (N, Lq, M * L * P) \
+            or reference_points.shape[:3] != (N, Lq, L):
+        raise RuntimeError("ms_deform_attn_forward_fused: inconsistent shapes")
+    out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+    with torch.cuda.device(value.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = lib.msda_hip_forward_fused_f32(
+            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), reference_points.data_ptr(),
+            int(reference_points.shape[-1]), sampling_offsets.data_ptr(), attention_logits.data_ptr(),
+            N, S, M, D, L, Lq, P, out.data_ptr(), ctypes.c_void_p(stream))
+    if rc != 0:
+        _raise(rc)
+    return out

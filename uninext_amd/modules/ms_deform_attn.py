@@ -1,12 +1,18 @@
 """`MSDeformAttn` -- the multi-scale deformable attention layer that owns the operator.
 
-Host-side mirror of the reference's ops/modules/ms_deform_attn.py:30-116: same constructor
-arguments, parameter names (`sampling_offsets`, `attention_weights`, `value_proj`,
-`output_proj` -- reference checkpoints load unchanged), initialisation (:54-76), argument
-meaning and errors of `forward` (:79-116).  The four projections stay PyTorch-ROCm GEMMs
-(rocBLAS/hipBLASLt); the sampling itself is `MSDeformAttnFunction` -> libmsda_hip.so.
+Host-side mirror of the reference's ops/modules/ms_deform_attn.py:30-116: same constructor arguments, parameter
+names (`sampling_offsets`, `attention_weights`, `value_proj`, `output_proj` -- reference checkpoints load unchanged),
+initialisation (:54-76), argument meaning and errors of `forward` (:79-116).  The four projections stay
+PyTorch-ROCm GEMMs (rocBLAS / hipBLASLt).  The sampling runs in libmsda_hip.so:
+
+  * when gradients are needed: softmax + sampling locations in PyTorch, then `MSDeformAttnFunction` (autograd),
+    exactly the reference's data flow;
+  * otherwise (inference): `ms_deform_attn_forward_fused` -- the kernel takes the raw Linear outputs and the
+    reference points and does softmax, location arithmetic and sampling in one pass.
+    Set `MSDeformAttn.fuse_prologue = False` (or env UNINEXT_AMD_NO_FUSED=1) to force the two-step path.
 """
 import math
+import os
 import warnings
 
 import torch
@@ -14,6 +20,7 @@ import torch.nn.functional as F
 from torch import nn
 from torch.nn.init import constant_, xavier_uniform_
 
+from .. import ext as MSDA
 from ..functions import MSDeformAttnFunction
 
 
@@ -24,6 +31,8 @@ def _is_power_of_2(n):
 
 
 class MSDeformAttn(nn.Module):
+    fuse_prologue = os.environ.get("UNINEXT_AMD_NO_FUSED", "0") != "1"
+
     def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4):
         super().__init__()
         if d_model % n_heads != 0:
@@ -58,32 +67,52 @@ class MSDeformAttn(nn.Module):
         xavier_uniform_(self.output_proj.weight.data)
         constant_(self.output_proj.bias.data, 0.0)
 
+    # -- the two ways to run the sampling ---------------------------------------------------------------------
+    def _sample_autograd(self, value, shapes, level_start, reference_points, offsets, logits):
+        """Reference data flow (:99-113): PyTorch prologue, then the differentiable operator."""
+        N, Lq = offsets.shape[:2]
+        M, L, P = self.n_heads, self.n_levels, self.n_points
+        offsets = offsets.view(N, Lq, M, L, P, 2)
+        weights = F.softmax(logits.view(N, Lq, M, L * P), -1).view(N, Lq, M, L, P)
+        if reference_points.shape[-1] == 2:
+            wh = torch.stack([shapes[..., 1], shapes[..., 0]], -1)
+            locations = reference_points[:, :, None, :, None, :] + offsets / wh[None, None, None, :, None, :]
+        else:
+            locations = reference_points[:, :, None, :, None, :2] \
+                + offsets / P * reference_points[:, :, None, :, None, 2:] * 0.5
+        return MSDeformAttnFunction.apply(value, shapes, level_start, locations, weights, self.im2col_step)
+
+    def _can_fuse(self, value, reference_points, offsets, logits):
+        if not self.fuse_prologue or not MSDA.fused_forward_supported(value, reference_points, self.n_levels,
+                                                                      self.n_points):
+            return False
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (value, reference_points, offsets, logits)):
+            return False   # the fused entry point has no backward
+        return all(t.is_contiguous() for t in (value, reference_points, offsets, logits))
+
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
                 input_padding_mask=None):
         """query (N, Lq, C); reference_points (N, Lq, n_levels, 2|4) in [0,1]; input_flatten (N, sum HW, C);
         input_spatial_shapes (n_levels, 2) int64 (H, W); input_level_start_index (n_levels,) int64;
         input_padding_mask (N, sum HW) bool, True = padding.  Returns (N, Lq, C)."""
-        N, Len_q, _ = query.shape
         N, Len_in, _ = input_flatten.shape
         assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == Len_in
+        if reference_points.shape[-1] not in (2, 4):
+            raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(
+                reference_points.shape[-1]))
 
         value = self.value_proj(input_flatten)
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], float(0))
         value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
-        offsets = self.sampling_offsets(query).view(N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
-        weights = self.attention_weights(query).view(N, Len_q, self.n_heads, self.n_levels * self.n_points)
-        weights = F.softmax(weights, -1).view(N, Len_q, self.n_heads, self.n_levels, self.n_points)
-        if reference_points.shape[-1] == 2:
-            wh = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)
-            locations = reference_points[:, :, None, :, None, :] + offsets / wh[None, None, None, :, None, :]
-        elif reference_points.shape[-1] == 4:
-            locations = reference_points[:, :, None, :, None, :2] \
-                + offsets / self.n_points * reference_points[:, :, None, :, None, 2:] * 0.5
+        offsets = self.sampling_offsets(query)        # (N, Lq, M*L*P*2)
+        logits = self.attention_weights(query)        # (N, Lq, M*L*P)
+
+        if self._can_fuse(value, reference_points, offsets, logits):
+            sampled = MSDA.ms_deform_attn_forward_fused(value, input_spatial_shapes, input_level_start_index,
+                                                        reference_points, offsets, logits, self.n_points)
         else:
-            raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(
-                reference_points.shape[-1]))
-        output = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index, locations,
-                                            weights, self.im2col_step)
-        return self.output_proj(output)
+            sampled = self._sample_autograd(value, input_spatial_shapes, input_level_start_index, reference_points,
+                                            offsets, logits)
+        return self.output_proj(sampled)
