@@ -1,0 +1,50 @@
+/*
+ * include/dynmask_hip.h -- C ABI of the CondInst-style dynamic mask head of UNINEXT on MI355X (gfx950), part of
+ * libmsda_hip.so.  SURVEY.md 8(f) rank 2: the step after the decoder on the inference path.
+ *
+ * Replaces, for inference, the body of DDETRSegmUniDN.dynamic_mask_with_coords
+ * (projects/UNINEXT/uninext/models/ddetrs_dn.py:755-844) between "build mask_head_inputs" and "upsample":
+ *   - compute_locations + relative coordinates (ddetrs_dn.py:765-784, 1199-1212),
+ *   - the repeat/cat that materialises [1, n_inst*(C+2), H, W] (ddetrs_dn.py:786-808; 1.2 GB at 1800 instances),
+ *   - parse_dynamic_params (ddetrs_dn.py:1148-1171) and the three grouped 1x1 convolutions of
+ *     mask_heads_forward (ddetrs_dn.py:734-752): (C+2) -> 8 -> 8 -> 1 with ReLU between,
+ * by one kernel that keeps the C mask-feature channels of a pixel in registers and walks the instances of the
+ * image with their 169 parameters staged in LDS; and aligned_bilinear (ddetrs_dn.py:1174-1196) by a second one.
+ *
+ * All pointers are device pointers except `num_insts` (host), contiguous fp32 unless noted; `stream` is a
+ * hipStream_t as void*.  Kernels are only enqueued.  Returns 0, a negative DYNMASK_ERR_*, or a positive hipError_t;
+ * the message is available from msda_hip_last_error().
+ */
+#ifndef DYNMASK_HIP_H_
+#define DYNMASK_HIP_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DYNMASK_ERR_NULL_POINTER (-1)
+#define DYNMASK_ERR_BAD_DIMS (-2)
+#define DYNMASK_ERR_UNSUPPORTED (-5)   /* feature channels != 8: use the PyTorch composition */
+
+/*
+ * mask_feats   [batch, 8, H, W]            output of the mask-feature branch (hidden_dim / 32 = 8 channels)
+ * inst_xy      [n_inst_all, 2]             instance reference points (x, y) in input-image pixels
+ * params       [n_inst_all, 169]           controller output: w0 (8 x 10) w1 (8 x 8) w2 (1 x 8) b0 (8) b1 (8) b2 (1);
+ *                                          with rel_coord == 0: w0 is 8 x 8 and a row has 153 values
+ * num_insts    [batch] (HOST ints)         instances per image, in order; n_inst_all = sum
+ * out_logits   [n_inst_all, H, W]          mask logits at the feature stride
+ * stride       mask_feat_stride (8): pixel (y, x) sits at (x * stride + stride / 2, y * stride + stride / 2)
+ */
+int dynmask_hip_forward_f32(const float* mask_feats, const float* inst_xy, const float* params,
+                            const int* num_insts, int batch, int channels, int H, int W, int stride,
+                            int rel_coord, float* out_logits, void* stream);
+
+/*
+ * aligned_bilinear (ddetrs_dn.py:1174-1196): in [n, h, w] -> out [n, factor*h, factor*w]; factor >= 1.
+ */
+int aligned_bilinear_hip_f32(const float* in, int n, int h, int w, int factor, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DYNMASK_HIP_H_ */

@@ -40,6 +40,17 @@ def test_every_declared_symbol_is_exported(lib):
         getattr(raw, n)
 
 
+def test_dynmask_header_symbols_are_exported(lib):
+    import re
+    from uninext_amd import _lib
+    text = open(os.path.join(ROOT, "include", "dynmask_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(\w+_hip_\w+)\s*\(", text)))
+    assert names == sorted(_lib.DYNMASK_EXPORTS)
+    for n in names:
+        assert hasattr(lib, n), n
+
+
 def test_abi_version_and_variant_table(lib):
     from uninext_amd import _lib
     assert lib.msda_hip_abi_version() == _lib.ABI_VERSION == 1

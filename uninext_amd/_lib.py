@@ -14,6 +14,8 @@ EXPORTS = (
     "msda_hip_set_variant", "msda_hip_get_variant", "msda_hip_variant_name", "msda_hip_last_kernel",
 )
 
+DYNMASK_EXPORTS = ("dynmask_hip_forward_f32", "aligned_bilinear_hip_f32")   # include/dynmask_hip.h
+
 _lib = None
 
 
@@ -38,6 +40,9 @@ def load():
         g.argtypes, g.restype = [p, p, p, p, p, p, i, i, i, i, i, i, i, p, p, p, p], i
     lib.msda_hip_forward_fused_f32.argtypes = [p, p, p, p, i, p, p, i, i, i, i, i, i, i, p, p]
     lib.msda_hip_forward_fused_f32.restype = i
+    lib.dynmask_hip_forward_f32.argtypes = [p, p, p, p, i, i, i, i, i, i, p, p]
+    lib.dynmask_hip_forward_f32.restype = i
+    lib.aligned_bilinear_hip_f32.argtypes, lib.aligned_bilinear_hip_f32.restype = [p, i, i, i, i, p, p], i
     lib.msda_hip_set_variant.argtypes, lib.msda_hip_set_variant.restype = [i, i], i
     lib.msda_hip_get_variant.argtypes, lib.msda_hip_get_variant.restype = [i], i
     lib.msda_hip_variant_name.argtypes, lib.msda_hip_variant_name.restype = [i, i], s

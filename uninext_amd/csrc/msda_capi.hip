@@ -85,6 +85,9 @@ int backward_impl(const T* grad_out, const T* value, const int64_t* shapes, cons
 
 extern "C" {
 
+// shared error slot for the other entry points of the library (dynmask.hip)
+int dynmask_set_error(int code, const char* what) { return fail(code, what); }
+
 int msda_hip_abi_version(void) { return MSDA_HIP_ABI_VERSION; }
 const char* msda_hip_last_error(void) { return g_err; }
 

@@ -129,3 +129,52 @@ def ms_deform_attn_forward_fused(value, spatial_shapes, level_start_index, refer
     if rc != 0:
         _raise(rc)
     return out
+
+
+# ---- dynamic mask head (include/dynmask_hip.h) -------------------------------------------------------------
+def dynmask_supported(mask_feats):
+    return mask_feats.is_cuda and mask_feats.dtype == torch.float32 and mask_feats.dim() == 4 and mask_feats.shape[1] == 8
+
+
+def dynmask_forward(mask_feats, inst_xy, params, num_insts, stride, rel_coord=True):
+    """Per-instance 3-layer 1x1 dynamic conv (ddetrs_dn.py:734-752 on the inputs of :765-808) -> [n_inst, H, W]."""
+    lib = _lib.load()
+    for name, t in (("mask_feats", mask_feats), ("inst_xy", inst_xy), ("params", params)):
+        _check(name, t, mask_feats.device)
+        if t.dtype != torch.float32:
+            raise RuntimeError("%s must be float32" % name)
+    N, C, H, W = mask_feats.shape
+    counts = [int(n) for n in num_insts]
+    n_all = sum(counts)
+    want = (C + 2 if rel_coord else C) * 8 + 8 * 8 + 8 + 8 + 8 + 1
+    if len(counts) != N or inst_xy.shape != (n_all, 2) or params.shape != (n_all, want):
+        raise RuntimeError("dynmask_forward: inconsistent shapes")
+    out = torch.empty((n_all, H, W), dtype=torch.float32, device=mask_feats.device)
+    arr = (ctypes.c_int * max(N, 1))(*counts)
+    with torch.cuda.device(mask_feats.device):
+        rc = lib.dynmask_hip_forward_f32(mask_feats.data_ptr(), inst_xy.data_ptr(), params.data_ptr(), arr, N, C, H, W,
+                                         int(stride), int(bool(rel_coord)), out.data_ptr(),
+                                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc != 0:
+        _raise(rc)
+    return out
+
+
+def aligned_bilinear_forward(x, factor):
+    """aligned_bilinear (ddetrs_dn.py:1174-1196) of a [n, 1, h, w] or [n, h, w] fp32 GPU tensor."""
+    lib = _lib.load()
+    _check("tensor", x, x.device)
+    if x.dtype != torch.float32:
+        raise RuntimeError("tensor must be float32")
+    squeeze = x.dim() == 4
+    if squeeze and x.shape[1] != 1:
+        raise RuntimeError("aligned_bilinear_forward: expected [n, 1, h, w]")
+    n, h, w = x.shape[0], x.shape[-2], x.shape[-1]
+    f = int(factor)
+    out = torch.empty((n, 1, f * h, f * w) if squeeze else (n, f * h, f * w), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.aligned_bilinear_hip_f32(x.data_ptr(), n, h, w, f, out.data_ptr(),
+                                          ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc != 0:
+        _raise(rc)
+    return out

@@ -1,0 +1,107 @@
+"""Dynamic (per-instance) mask head of UNINEXT's CondInst branch -- SURVEY.md 8(f) rank 2.
+
+Host-side mirror of `DDETRSegmUniDN.dynamic_mask_with_coords` (projects/UNINEXT/uninext/models/ddetrs_dn.py:755-844)
+and of the helpers it uses (`mask_heads_forward` :734-752, `parse_dynamic_params` :1148-1171, `aligned_bilinear`
+:1174-1196, `compute_locations` :1199-1212): same arguments, same output `[1, n_inst_all, H*f, W*f]`.
+
+Inference on the GPU (fp32, 8 mask-feature channels, no gradients needed) runs two HIP kernels
+(include/dynmask_hip.h): the three per-instance 1x1 convolutions with the relative-coordinate channels generated on
+the fly -- the reference's `[1, n_inst*(C+2), H, W]` repeat/cat input (1.2 GB at 1800 instances) is never built --
+and `aligned_bilinear`.  When gradients are required (training) or the geometry is unsupported, a PyTorch
+composition is used that is algebraically the same but also non-materialising: the feature part of the first layer
+is one batched matmul against the shared feature map.  `use_raft` up-sampling is not covered (USE_RAFT is False in
+every shipped config, uninext/config.py:178).
+"""
+import torch
+import torch.nn.functional as F
+
+from . import ext as _ext
+
+DYNAMIC_MASK_CHANNELS = 8   # ddetrs_dn.py:46
+
+
+def parse_dynamic_params(params, in_channels, rel_coord=True):
+    """[n, num_params] -> (w0 [n,8,cin], w1 [n,8,8], w2 [n,1,8], b0 [n,8], b1 [n,8], b2 [n,1]); order of
+    ddetrs_dn.py:53-66: all weights first, then all biases."""
+    ch = DYNAMIC_MASK_CHANNELS
+    cin = in_channels + 2 if rel_coord else in_channels
+    n = params.shape[0]
+    assert params.dim() == 2 and params.shape[1] == cin * ch + ch * ch + ch + ch + ch + 1
+    w0, w1, w2, b0, b1, b2 = torch.split_with_sizes(params, [cin * ch, ch * ch, ch, ch, ch, 1], dim=1)
+    return w0.reshape(n, ch, cin), w1.reshape(n, ch, ch), w2.reshape(n, 1, ch), b0, b1, b2
+
+
+def compute_locations(h, w, device, stride=1):
+    xs = torch.arange(0, w * stride, step=stride, dtype=torch.float32, device=device)
+    ys = torch.arange(0, h * stride, step=stride, dtype=torch.float32, device=device)
+    yy, xx = torch.meshgrid(ys, xs, indexing="ij")
+    return torch.stack((xx.reshape(-1), yy.reshape(-1)), dim=1) + stride // 2
+
+
+def _aligned_bilinear_torch(tensor, factor):
+    if factor == 1:
+        return tensor
+    h, w = tensor.shape[2:]
+    t = F.pad(tensor, pad=(0, 1, 0, 1), mode="replicate")
+    t = F.interpolate(t, size=(factor * h + 1, factor * w + 1), mode="bilinear", align_corners=True)
+    t = F.pad(t, pad=(factor // 2, 0, factor // 2, 0), mode="replicate")
+    return t[:, :, :factor * h, :factor * w]
+
+
+def aligned_bilinear(tensor, factor):
+    assert tensor.dim() == 4 and factor >= 1 and int(factor) == factor
+    factor = int(factor)
+    if factor == 1:
+        return tensor
+    needs_grad = torch.is_grad_enabled() and tensor.requires_grad
+    if tensor.is_cuda and tensor.dtype == torch.float32 and tensor.shape[1] == 1 and not needs_grad:
+        return _ext.aligned_bilinear_forward(tensor.contiguous(), factor)
+    return _aligned_bilinear_torch(tensor, factor)
+
+
+def _dynamic_convs_torch(mask_feats, inst_xy, params, num_insts, stride, rel_coord):
+    """Differentiable composition, [n_all, H, W]."""
+    n_img, c, h, w = mask_feats.shape
+    w0, w1, w2, b0, b1, b2 = parse_dynamic_params(params, c, rel_coord)
+    loc = compute_locations(h, w, mask_feats.device, stride)            # [HW, 2]
+    outs, first = [], 0
+    for b, cnt in enumerate(num_insts):
+        sl = slice(first, first + cnt)
+        feat = mask_feats[b].reshape(c, h * w)                           # shared by the image's instances
+        h0 = torch.matmul(w0[sl, :, (2 if rel_coord else 0):], feat) + b0[sl, :, None]
+        if rel_coord:
+            rel = inst_xy[sl, None, :] - loc[None, :, :]                 # [cnt, HW, 2]
+            h0 = h0 + torch.matmul(w0[sl, :, :2], rel.transpose(1, 2))
+        h1 = torch.relu(torch.bmm(w1[sl], torch.relu(h0)) + b1[sl, :, None])
+        outs.append((torch.bmm(w2[sl], h1) + b2[sl, :, None]).reshape(cnt, h, w))
+        first += cnt
+    return torch.cat(outs, 0) if outs else mask_feats.new_zeros((0, h, w))
+
+
+def dynamic_mask_logits(mask_feats, reference_points, mask_head_params, num_insts, mask_feat_stride, rel_coord=True):
+    """Mask logits at the feature stride, [n_inst_all, 1, H, W] (ddetrs_dn.py:765-822)."""
+    n_img, c, h, w = mask_feats.shape
+    inst_xy = reference_points.reshape(-1, 2).float()
+    params = torch.flatten(mask_head_params, 0, 1)
+    counts = [int(n) for n in num_insts]
+    needs_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (mask_feats, reference_points, mask_head_params))
+    if _ext.dynmask_supported(mask_feats) and not needs_grad and params.dtype == torch.float32:
+        logits = _ext.dynmask_forward(mask_feats.contiguous(), inst_xy.contiguous(), params.contiguous(), counts,
+                                      mask_feat_stride, rel_coord)
+    else:
+        logits = _dynamic_convs_torch(mask_feats, inst_xy, params, counts, mask_feat_stride, rel_coord)
+    return logits.reshape(-1, 1, h, w)
+
+
+def dynamic_mask_with_coords(mask_feats, reference_points, mask_head_params, num_insts, mask_feat_stride,
+                             rel_coord=True, mask_out_stride=4):
+    """mask_feats [N, C, H, W]; reference_points [1, n_all, 2] (input pixels); mask_head_params [1, n_all, P];
+    num_insts per image.  Returns mask logits [1, n_all, H*f, W*f], f = mask_feat_stride / mask_out_stride."""
+    assert mask_feat_stride >= mask_out_stride and mask_feat_stride % mask_out_stride == 0
+    n_all = reference_points.shape[1]
+    h, w = mask_feats.shape[2:]
+    if n_all == 0:   # the reference returns the (empty) inputs plus a zero that keeps the graph connected (:819-821)
+        return mask_feats.new_zeros((1, 0, h, w)) + torch.sum(mask_head_params) * 0.0
+    logits = dynamic_mask_logits(mask_feats, reference_points, mask_head_params, num_insts, mask_feat_stride, rel_coord)
+    logits = aligned_bilinear(logits, int(mask_feat_stride / mask_out_stride))
+    return logits.reshape(1, -1, logits.shape[-2], logits.shape[-1])
