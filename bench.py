@@ -163,6 +163,8 @@ def main():
     enc, dec = build_inputs(args.flavour, rank)
     S = enc[0]["value"].shape[1]
 
+    call(enc[0])
+    enc_kernel = _lib.last_kernel("forward")   # the kernel the encoder launches take (decoder calls may differ)
     for _ in range(max(args.warmup, 0)):
         run_step(enc, dec)
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -175,7 +177,6 @@ def main():
     torch.cuda.synchronize()
     barrier(world)
     elapsed = max_over_ranks(time.perf_counter() - t0, world)
-    enc_kernel = _lib.last_kernel("forward")
 
     if rank == 0:
         enc_ms = sum(a.elapsed_time(b) for a, b in events) / (args.steps * ENC_LAYERS)  # per encoder launch

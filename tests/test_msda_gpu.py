@@ -128,7 +128,7 @@ def test_quarter_scale_r50_vs_oracle(kind, flavour, dev, api):
     x = workloads.make_inputs(kind, flavour, batch=2, levels=levels, num_query=None if kind == "encoder" else 300,
                               seed=21, device=dev)
     out = MSDA.ms_deform_attn_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], 64)
-    assert lib.last_kernel("forward") == "msda_fwd_lanegroup"
+    assert lib.last_kernel("forward") == ("msda_fwd_lg3" if x["loc"].shape[1] >= 1024 else "msda_fwd_lanegroup")
     ref = msda_oracle.forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
     assert max_abs(_np(out), ref) < 1e-4
     go = torch.randn(out.shape, generator=torch.Generator().manual_seed(5)).to(dev)
@@ -239,7 +239,8 @@ def test_tiled_forward_head_point_counts(M, L, P, variant, dev, api):
     ("encoder", "model", ((64, 80), (32, 40), (16, 20), (17, 17))),        # last level 289 px: too big, nothing resident
     ("decoder", "model", ((64, 80), (32, 40), (16, 20), (8, 10))),         # Lq = 5000 arbitrary queries
 ])
-def test_lgcl_forward_vs_oracle(kind, flavour, levels, dev, api):
+@pytest.mark.parametrize("variant", ["msda_fwd_lgcl", "msda_fwd_lg3"])
+def test_lgcl_forward_vs_oracle(kind, flavour, levels, variant, dev, api):
     """Lane-group kernel with the last pyramid level resident in LDS (any query set, any sampling pattern)."""
     from oracle import msda_oracle
     from uninext_amd import workloads
@@ -247,13 +248,14 @@ def test_lgcl_forward_vs_oracle(kind, flavour, levels, dev, api):
     x = workloads.make_inputs(kind, flavour, batch=2, levels=levels, num_query=None if kind == "encoder" else 5000,
                               seed=41, device=dev)
     x["loc"][1, 7, 3, 3, 2, 0] = float("nan")
-    lib.set_variant("forward", "msda_fwd_lgcl")
+    lib.set_variant("forward", variant)
     try:
         out = MSDA.ms_deform_attn_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], 64)
     finally:
         lib.set_variant("forward", "auto")
     S = x["value"].shape[1]
-    assert lib.last_kernel("forward") == ("msda_fwd_lgcl" if x["loc"].shape[1] >= 4096 else "msda_fwd_lanegroup"), S
+    min_q = 4096 if variant == "msda_fwd_lgcl" else 1024
+    assert lib.last_kernel("forward") == (variant if x["loc"].shape[1] >= min_q else "msda_fwd_lanegroup"), S
     idx = torch.cat([torch.arange(0, 600), torch.arange(x["loc"].shape[1] - 600, x["loc"].shape[1])]).to(dev)
     ref = msda_oracle.forward(x["value"], x["shapes"], x["lsi"], x["loc"][:, idx].contiguous(),
                               x["attn"][:, idx].contiguous())
@@ -272,8 +274,8 @@ def test_full_size_encoder_forward(flavour, dev, api):
     out = MSDA.ms_deform_attn_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], 64)
     assert out.shape == (2, 22223, 256)
     auto_kernel = lib.last_kernel("forward")
-    assert auto_kernel in ("msda_fwd_lgcl", "msda_fwd_tiled", "msda_fwd_lanegroup")
-    for other in ("msda_fwd_lanegroup", "msda_fwd_tiled_l0", "msda_fwd_lgcl"):   # every fast kernel, full size
+    assert auto_kernel == "msda_fwd_lg3"
+    for other in ("msda_fwd_lanegroup", "msda_fwd_tiled_l0", "msda_fwd_lgcl", "msda_fwd_lg3"):   # every fast kernel
         lib.set_variant("forward", other)
         try:
             out_o = MSDA.ms_deform_attn_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], 64)

@@ -4,7 +4,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmsda_hip.so")
+# MSDA_HIP_LIB points the binding at another build of the SAME library (A/B builds of experimental kernels)
+LIB_PATH = os.environ.get("MSDA_HIP_LIB") or os.path.join(_HERE, "lib", "libmsda_hip.so")
 
 ABI_VERSION = 1
 EXPORTS = (

@@ -23,7 +23,6 @@
 
 namespace msda {
 
-constexpr bool kTiledIsDefault = false;
 
 // ------------------------------------------------------------------------------------------------
 template <typename T>
@@ -465,6 +464,170 @@ msda_fwd_lgcl(const float* __restrict__ value, const int64_t* __restrict__ shape
   else run(std::integral_constant<int, LPT / P>{});
 }
 
+// ------------------------------------------------------------------------------------------------
+// msda_fwd_lg3: one-shot (non-persistent) 1024-thread workgroups of 128 queries x 1 head, last pyramid level
+// resident in LDS.  Lessons of msda_fwd_lgcl (profiles/): the gather needs ~32 waves per CU in flight;
+// a persistent 4-wave workgroup that owns 54 KB of LDS leaves 12 and becomes latency bound (68 % of wave cycles in
+// s_waitcnt).  Here 16 waves share one 35 KB copy and the sample records are built 8 samples at a time (2.1 KB per
+// wave instead of 4.2), so two workgroups = 32 waves fit a CU and the kernel must stay within 64 VGPRs.
+constexpr int kL3Threads = 1024;
+constexpr int kL3RecPair = 8 * 32 + 16;
+constexpr int kL3LdsBytes = kLevelTableBytes + (kClSlots + 1) * 128 + (kL3Threads / 8) * kL3RecPair;
+
+__global__ void __launch_bounds__(kL3Threads, 8)
+msda_fwd_lg3(const float* __restrict__ value, const int64_t* __restrict__ shapes,
+             const int64_t* __restrict__ lsi, const float* __restrict__ loc,
+             const float* __restrict__ attn, Dims d, float* __restrict__ out) {
+  constexpr int G = 8, LPT = 16, P = 4, kPairs = kL3Threads / G;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* smp_H = reinterpret_cast<int*>(smem);
+  int* smp_W = smp_H + kMaxLP;
+  int* smp_start = smp_W + kMaxLP;
+  char* cl_base = smem + kLevelTableBytes;
+  char* rec_base = cl_base + (kClSlots + 1) * 128;
+  const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+  const int tid = threadIdx.x;
+  if (tid < LPT) {
+    const int l = tid / P;
+    smp_H[tid] = (int)shapes[2 * l];
+    smp_W[tid] = (int)shapes[2 * l + 1];
+    smp_start[tid] = (int)lsi[l];
+  }
+  __syncthreads();
+  const int res_pix0 = __builtin_amdgcn_readfirstlane(smp_start[LPT - 1]);   // first pixel of the last level
+  const int nres_all = d.S - res_pix0;
+  const bool fits = nres_all <= kClSlots;          // uniform; otherwise the last level also takes the L1 path
+  const int nres = fits ? nres_all : 0;
+
+  const int b = blockIdx.y;
+  const int m = blockIdx.x % d.M;
+  const uint32_t pix_bytes = (uint32_t)d.M * 128u;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(value) + (int64_t)b * d.S * d.M * 32, 0, (int)((uint32_t)d.S * pix_bytes), 0x00020000);
+  const uint32_t head_off = (uint32_t)m * 128u;
+  for (int i = tid >> 3; i <= nres && fits; i += kL3Threads / 8) {   // slot `nres` stays zero: dead corners read it
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (i < nres) v = buffer_load_f32x4(rsrc, (uint32_t)(res_pix0 + i) * pix_bytes + (uint32_t)(tid & 7) * 16u, head_off);
+    *reinterpret_cast<f32x4*>(cl_base + i * 128 + (tid & 7) * 16) = v;
+  }
+
+  const int g = tid / G, j = tid % G;
+  const int q = (blockIdx.x / d.M) * kPairs + g;
+  const bool live = q < d.Lq;
+  const int64_t pair = ((int64_t)b * d.Lq + (live ? q : 0)) * d.M + m;
+  char* rec = rec_base + g * kL3RecPair;
+  const uint32_t lane_off = (uint32_t)j * 16u;
+  const uint32_t cl_addr0 = smem_base + kLevelTableBytes;
+  const uint32_t zero_slot = cl_addr0 + (uint32_t)nres * 128u;
+
+  // lane j prepares sample j of pass 0 (levels 0, 1) and sample 8 + j of pass 1 (levels 2, 3)
+  float2 lc0 = make_float2(0.f, 0.f), lc1 = make_float2(0.f, 0.f);
+  float at0 = 0.f, at1 = 0.f;
+  if (live) {
+    lc0 = *reinterpret_cast<const float2*>(loc + pair * (2 * LPT) + 2 * j);
+    lc1 = *reinterpret_cast<const float2*>(loc + pair * (2 * LPT) + 2 * (8 + j));
+    at0 = attn[pair * LPT + j];
+    at1 = attn[pair * LPT + 8 + j];
+  }
+  auto prepare = [&](int s, int slot, float lx, float ly, float a, bool resident) {
+    const int H = smp_H[s], W = smp_W[s];
+    const Sample<float> sm = make_sample<float>(lx, ly, H, W);
+    const float wa = sm.hh * a, wb = sm.lh * a;
+    float4 w;
+    w.x = (live && sm.ok1) ? wa * sm.hw : 0.f;
+    w.y = (live && sm.ok2) ? wa * sm.lw : 0.f;
+    w.z = (live && sm.ok3) ? wb * sm.hw : 0.f;
+    w.w = (live && sm.ok4) ? wb * sm.lw : 0.f;
+    const int pix1 = smp_start[s] + sm.h_low * W + sm.w_low;
+    u32x4 o;
+    if (resident) {
+      const uint32_t a1 = cl_addr0 + (uint32_t)(pix1 - res_pix0) * 128u;
+      o[0] = sm.ok1 ? a1 : zero_slot;
+      o[1] = sm.ok2 ? a1 + 128u : zero_slot;
+      o[2] = sm.ok3 ? a1 + (uint32_t)W * 128u : zero_slot;
+      o[3] = sm.ok4 ? a1 + (uint32_t)(W + 1) * 128u : zero_slot;
+    } else {
+      const uint32_t o1 = (uint32_t)pix1 * pix_bytes;
+      o[0] = sm.ok1 ? o1 : kOobOffset;
+      o[1] = sm.ok2 ? o1 + pix_bytes : kOobOffset;
+      o[2] = sm.ok3 ? o1 + (uint32_t)W * pix_bytes : kOobOffset;
+      o[3] = sm.ok4 ? o1 + (uint32_t)(W + 1) * pix_bytes : kOobOffset;
+    }
+    *reinterpret_cast<float4*>(rec + slot * 32) = w;
+    *reinterpret_cast<u32x4*>(rec + slot * 32 + 16) = o;
+  };
+  auto wave_sync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  auto gather_global = [&](int slot) {
+    const float4 w = *reinterpret_cast<const float4*>(rec + slot * 32);
+    const u32x4 o = *reinterpret_cast<const u32x4*>(rec + slot * 32 + 16);
+    const f32x4 r1 = buffer_load_f32x4(rsrc, o[0] + lane_off, head_off);
+    const f32x4 r2 = buffer_load_f32x4(rsrc, o[1] + lane_off, head_off);
+    const f32x4 r3 = buffer_load_f32x4(rsrc, o[2] + lane_off, head_off);
+    const f32x4 r4 = buffer_load_f32x4(rsrc, o[3] + lane_off, head_off);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      acc[c] = fmaf(w.w, r4[c], fmaf(w.z, r3[c], fmaf(w.y, r2[c], fmaf(w.x, r1[c], acc[c]))));
+  };
+  auto gather_lds = [&](int slot) {
+    typedef const f32x4 __attribute__((address_space(3)))* lp;
+    const float4 w = *reinterpret_cast<const float4*>(rec + slot * 32);
+    const u32x4 o = *reinterpret_cast<const u32x4*>(rec + slot * 32 + 16);
+    const f32x4 r1 = *reinterpret_cast<lp>((uintptr_t)(o[0] + lane_off));
+    const f32x4 r2 = *reinterpret_cast<lp>((uintptr_t)(o[1] + lane_off));
+    const f32x4 r3 = *reinterpret_cast<lp>((uintptr_t)(o[2] + lane_off));
+    const f32x4 r4 = *reinterpret_cast<lp>((uintptr_t)(o[3] + lane_off));
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      acc[c] = fmaf(w.w, r4[c], fmaf(w.z, r3[c], fmaf(w.y, r2[c], fmaf(w.x, r1[c], acc[c]))));
+  };
+
+  // pass 0: samples 0..7 (levels 0 and 1), all through the L1 path; overlaps the other waves' staging
+  prepare(j, j, lc0.x, lc0.y, at0, false);
+  wave_sync();
+#pragma unroll
+  for (int s = 0; s < 8; ++s) gather_global(s);
+  wave_sync();
+  // pass 1: samples 8..15 (levels 2 and 3); level 3 (slots 4..7) comes from the LDS copy
+  prepare(8 + j, j, lc1.x, lc1.y, at1, fits && j >= 4);
+  __syncthreads();   // the level copy is complete (and the records of this wave are visible)
+#pragma unroll
+  for (int s = 0; s < 4; ++s) gather_global(s);
+  if (fits) {
+#pragma unroll
+    for (int s = 4; s < 8; ++s) gather_lds(s);
+  } else {
+#pragma unroll
+    for (int s = 4; s < 8; ++s) gather_global(s);
+  }
+  if (live) __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(out + pair * 32 + 4 * j));
+}
+
+static inline bool lg3_ok(const Dims& d) {
+  return d.D == 32 && d.P == 4 && d.L == 4 && (int64_t)d.S * d.M * 128 < (int64_t)kOobOffset && d.N <= 65535 &&
+         d.Lq >= 1024;   // a 128-query workgroup copies 35 KB: pointless for a handful of queries
+}
+
+static int launch_lg3(const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc,
+                      const float* attn, const Dims& d, float* out, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_fwd_lg3),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kL3LdsBytes);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  constexpr int kPairs = kL3Threads / 8;
+  dim3 grid((unsigned)(d.M * ((d.Lq + kPairs - 1) / kPairs)), (unsigned)d.N);
+  hipLaunchKernelGGL(msda_fwd_lg3, grid, dim3(kL3Threads), kL3LdsBytes, stream, value, shapes, lsi, loc, attn, d, out);
+  return (int)hipGetLastError();
+}
+
 static inline bool lgcl_ok(const Dims& d) {
   return d.D == 32 && d.P == 4 && d.L == 4 && (int64_t)d.S * d.M * 128 < (int64_t)kOobOffset && d.N <= 65535 &&
          d.Lq >= 4096;   // the resident copy is amortised over >= 2 query chunks per workgroup
@@ -513,8 +676,14 @@ int launch_forward<float>(int variant, const float* value, const int64_t* shapes
   int G = 0;
   const bool lg = lanegroup_ok(d, &G);
   const bool tl = tiled_forward_ok(d);
-  // the tiled kernel is selected automatically only once it beats the lane-group kernel (kbench A/B)
-  if (variant == kAuto) variant = (kTiledIsDefault && tl && d.S >= 4096) ? kTiled : (lg ? kLaneGroup : kGeneric);
+  // kbench A/B (profiles/): msda_fwd_lg3 beats msda_fwd_lanegroup by 14-20 % from ~1000 queries on; the tiled and
+  // lgcl kernels lose and stay opt-in
+  if (variant == kAuto) variant = lg3_ok(d) ? kLaneGroupL3 : (lg ? kLaneGroup : kGeneric);
+  if (variant == kLaneGroupL3 && !lg3_ok(d)) variant = kLaneGroup;
+  if (variant == kLaneGroupL3) {
+    *kernel_name = "msda_fwd_lg3";
+    return launch_lg3(value, shapes, lsi, loc, attn, d, out, stream);
+  }
   if (variant == kLaneGroupCL && !lgcl_ok(d)) variant = kLaneGroup;
   if (variant == kLaneGroupCL) {
     *kernel_name = "msda_fwd_lgcl";
