@@ -239,7 +239,7 @@ def test_tiled_forward_head_point_counts(M, L, P, variant, dev, api):
     ("encoder", "model", ((64, 80), (32, 40), (16, 20), (17, 17))),        # last level 289 px: too big, nothing resident
     ("decoder", "model", ((64, 80), (32, 40), (16, 20), (8, 10))),         # Lq = 5000 arbitrary queries
 ])
-@pytest.mark.parametrize("variant", ["msda_fwd_lgcl", "msda_fwd_lg3"])
+@pytest.mark.parametrize("variant", ["msda_fwd_lgcl", "msda_fwd_lg3", "msda_fwd_lgp"])
 def test_lgcl_forward_vs_oracle(kind, flavour, levels, variant, dev, api):
     """Lane-group kernel with the last pyramid level resident in LDS (any query set, any sampling pattern)."""
     from oracle import msda_oracle
@@ -275,7 +275,7 @@ def test_full_size_encoder_forward(flavour, dev, api):
     assert out.shape == (2, 22223, 256)
     auto_kernel = lib.last_kernel("forward")
     assert auto_kernel == "msda_fwd_lg3"
-    for other in ("msda_fwd_lanegroup", "msda_fwd_tiled_l0", "msda_fwd_lgcl", "msda_fwd_lg3"):   # every fast kernel
+    for other in ("msda_fwd_lanegroup", "msda_fwd_tiled_l0", "msda_fwd_lgcl", "msda_fwd_lg3", "msda_fwd_lgp"):   # every fast kernel
         lib.set_variant("forward", other)
         try:
             out_o = MSDA.ms_deform_attn_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], 64)

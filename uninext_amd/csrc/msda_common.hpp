@@ -82,7 +82,7 @@ int launch_backward(int variant, const T* grad_out, const T* value, const int64_
 
 // Variant numbering shared with include/msda_hip.h.
 enum Variant { kAuto = 0, kGeneric = 1, kLaneGroup = 2, kTiled = 3, kTiledL0 = 4, kTiledL0Big = 5, kLaneGroupCL = 6,
-               kLaneGroupL3 = 7, kNumVariants = 8 };
+               kLaneGroupL3 = 7, kLaneGroupP = 8, kNumVariants = 9 };
 
 // msda_fwd.hip: forward with the MSDeformAttn prologue (softmax + sampling locations) fused in.
 bool fused_forward_ok(const Dims& d, int ref_dim);
