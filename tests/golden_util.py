@@ -13,12 +13,17 @@ def _names():
 
 def golden_names():
     """MSDeformAttn operator fixtures (tests/golden/make_golden.py)."""
-    return [n for n in _names() if not n.startswith(("matcher_", "dynmask_"))]
+    return [n for n in _names() if not n.startswith(("matcher_", "dynmask_", "patch_"))]
 
 
 def dynmask_names():
     """Dynamic mask head fixtures (tests/golden/make_dynmask_golden.py), without the aligned_bilinear one."""
     return [n for n in _names() if n.startswith("dynmask_") and n != "dynmask_aligned_bilinear"]
+
+
+def patch_names():
+    """Patch-embedding fixtures (tests/golden/make_patch_embed_golden.py)."""
+    return [n for n in _names() if n.startswith("patch_")]
 
 
 def matcher_names():

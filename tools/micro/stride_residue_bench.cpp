@@ -13,7 +13,7 @@ typedef float f32x4 __attribute__((__vector_size__(16)));
 __global__ void __launch_bounds__(256) gather(const char* __restrict__ buf, int npix, int mode, int rot, int iters,
                                               int local, float* __restrict__ sink) {
   const int lane8 = threadIdx.x & 7, grp = threadIdx.x >> 3;   // 32 groups of 8 lanes, one 128-B line per group
-  int res = mode == 0 ? rot : ((blockIdx.x + rot) & 7);
+  int res = mode == 0 ? rot : ((blockIdx.x + rot) & 7);   // modes 1..3: one residue / head per XCD
   unsigned p = (blockIdx.x >> 3) * 2654435761u + grp * 40503u;
   const int base_pix = (int)(((long long)(blockIdx.x >> 3) * npix) / (gridDim.x >> 3));   // local mode: own band
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -27,7 +27,9 @@ __global__ void __launch_bounds__(256) gather(const char* __restrict__ buf, int 
     for (int u = 0; u < 8; ++u) {
       p = p * 1664525u + 1013904223u;
       int pix = local ? (base_pix + (int)((p >> 8) % 4096u)) % npix : (int)((p >> 8) % (unsigned)npix);
-      v[u] = *reinterpret_cast<const f32x4*>(buf + (size_t)pix * 1024 + res * 128 + lane8 * 16);
+      const size_t off = mode == 3 ? ((size_t)res * npix + pix) * 128     // head-major layout: dense slice per residue
+                                   : (size_t)pix * 1024 + res * 128;
+      v[u] = *reinterpret_cast<const f32x4*>(buf + off + lane8 * 16);
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) acc += v[u];
@@ -68,6 +70,10 @@ int main(int argc, char** argv) {
     for (int rot = 0; rot < 8; rot += 3) {
       const float us = run(1, rot, local);
       printf("  one residue per XCD (rot %d): %8.1f us  %6.2f TB/s\n", rot, us, lines * 128 / us * 1e-6);
+    }
+    for (int rot = 0; rot < 8; rot += 3) {
+      const float us = run(3, rot, local);
+      printf("  head-major layout (dense 5.7 MB slice per XCD) (rot %d): %8.1f us  %6.2f TB/s\n", rot, us, lines * 128 / us * 1e-6);
     }
     for (int rot = 0; rot < 8; rot += 3) {
       const float us = run(2, rot, local);

@@ -178,3 +178,47 @@ def aligned_bilinear_forward(x, factor):
     if rc != 0:
         _raise(rc)
     return out
+
+
+def patch_embed_supported(x, weight, stride, padding):
+    """True when include/patch_embed_hip.h has a kernel for this convolution (fp32, GPU, kernel == stride, no pad)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4 and weight.dim() == 4):
+        return False
+    k = weight.shape[2]
+    pad = tuple(padding) if isinstance(padding, (tuple, list)) else (padding, padding)
+    st = tuple(stride) if isinstance(stride, (tuple, list)) else (stride, stride)
+    return (weight.shape[3] == k and st == (k, k) and pad == (0, 0) and k in (2, 4, 8, 16)
+            and (weight.shape[1] * k * k) % 16 == 0 and x.shape[1] == weight.shape[1])
+
+
+def patch_embed_forward(x, weight, bias=None, channels_last=True):
+    """Non-overlapping-patch convolution (kernel == stride, no padding) on the matrix cores, exact fp32.
+
+    x [B, C, H, W], weight [E, C, k, k] (nn.Conv2d layout), bias [E] or None ->
+    [B, H // k, W // k, E] if channels_last (ViT PatchEmbed.forward, backbone/utils.py:182-186)
+    else [B, E, H // k, W // k] (nn.Conv2d, ConvNeXt stem / downsample convs, backbone/convnext.py:80,87).
+    Forward only (inference); under autograd use the PyTorch convolution.
+    """
+    lib = _lib.load()
+    _check("x", x, x.device)
+    _check("weight", weight, x.device)
+    if bias is not None:
+        _check("bias", bias, x.device)
+    for name, t in (("x", x), ("weight", weight), ("bias", bias)):
+        if t is not None and t.dtype != torch.float32:
+            raise RuntimeError("%s must be float32" % name)
+    if x.dim() != 4 or weight.dim() != 4 or weight.shape[2] != weight.shape[3] or x.shape[1] != weight.shape[1]:
+        raise RuntimeError("patch_embed_forward: expected x [B, C, H, W] and weight [E, C, k, k]")
+    if bias is not None and bias.shape != (weight.shape[0],):
+        raise RuntimeError("patch_embed_forward: bias must be [E]")
+    B, C, H, W = x.shape
+    E, k = weight.shape[0], weight.shape[2]
+    shape = (B, H // k, W // k, E) if channels_last else (B, E, H // k, W // k)
+    out = torch.empty(shape, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.patch_embed_hip_f32(x.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                     B, C, H, W, E, k, int(bool(channels_last)), out.data_ptr(),
+                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc != 0:
+        _raise(rc)
+    return out
