@@ -18,12 +18,14 @@
 // the patches and the NCHW store is coalesced too.
 #include "../../include/patch_embed_hip.h"
 
+#include <cstdlib>
+
 #include "msda_common.hpp"
 
 namespace patch_embed {
 
 constexpr int kThreads = 256;
-constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int BK = 16;
 constexpr int kPitch = 20;   // floats per LDS row: 16 + 4 pad (rows stay 16-byte aligned)
 
 using msda::f32x4;
@@ -33,12 +35,14 @@ struct Geom {
   int B, C, H, W, E, Hp, Wp, Mtot, K;
 };
 
-template <int KS, bool NHWC>
+template <int KS, bool NHWC, int BM, int BN>
 __global__ void __launch_bounds__(kThreads, 2)
 patch_embed_gemm(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, Geom g,
                  float* __restrict__ out) {
   constexpr int VW = KS >= 4 ? 4 : 2;                  // floats per A load (kx run)
-  constexpr int kALoads = BM * BK / VW / kThreads;     // 2 (float4) or 4 (float2)
+  constexpr int kALoads = BM * BK / VW / kThreads;     // 128 rows: 2 (float4) or 4 (float2)
+  constexpr int kBLoads = BN * BK / 4 / kThreads;
+  constexpr int TI = BM / 64, TJ = BN / 64;            // 32 x 32 MFMA tiles per wave (waves are 2 x 2)
   constexpr int kQ = BK / VW;                          // k groups per row
   __shared__ __attribute__((aligned(16))) float As[2][BM][kPitch];
   __shared__ __attribute__((aligned(16))) float Bs[2][BN][kPitch];
@@ -61,10 +65,10 @@ patch_embed_gemm(const float* __restrict__ x, const float* __restrict__ w, const
     const int py = sp / g.Wp, px = sp - py * g.Wp;
     a_base[i] = ((int64_t)b * g.C * g.H + (int64_t)py * KS) * g.W + (int64_t)px * KS;
   }
-  const float* b_ptr[2];
-  int b_row[2], b_kq[2];
+  const float* b_ptr[kBLoads];
+  int b_row[kBLoads], b_kq[kBLoads];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < kBLoads; ++i) {
     const int idx = tid + i * kThreads;
     b_row[i] = idx / 4;
     b_kq[i] = idx % 4;
@@ -75,7 +79,7 @@ patch_embed_gemm(const float* __restrict__ x, const float* __restrict__ w, const
 
   f32x4 a_reg[kALoads];
   float a_reg2[kALoads][2];
-  f32x4 b_reg[2];
+  f32x4 b_reg[kBLoads];
   auto load_tile = [&](int kt) {
 #pragma unroll
     for (int i = 0; i < kALoads; ++i) {
@@ -91,7 +95,7 @@ patch_embed_gemm(const float* __restrict__ x, const float* __restrict__ w, const
       }
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) b_reg[i] = *reinterpret_cast<const f32x4*>(b_ptr[i] + kt * BK);
+    for (int i = 0; i < kBLoads; ++i) b_reg[i] = *reinterpret_cast<const f32x4*>(b_ptr[i] + kt * BK);
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
@@ -104,17 +108,17 @@ patch_embed_gemm(const float* __restrict__ x, const float* __restrict__ w, const
       }
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(&Bs[buf][b_row[i]][b_kq[i] * 4]) = b_reg[i];
+    for (int i = 0; i < kBLoads; ++i) *reinterpret_cast<f32x4*>(&Bs[buf][b_row[i]][b_kq[i] * 4]) = b_reg[i];
   };
 
   // ---- main loop --------------------------------------------------------------------------------------------
-  const int wm = (wv >> 1) * 64, wn = (wv & 1) * 64;   // this wave's 64 x 64 corner of the tile
+  const int wm = (wv >> 1) * (BM / 2), wn = (wv & 1) * (BN / 2);   // this wave's corner of the tile
   const int r32 = lane & 31, half = lane >> 5;
-  f32x16 acc[2][2];
+  f32x16 acc[TI][TJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
-    for (int jn = 0; jn < 2; ++jn)
+    for (int jn = 0; jn < TJ; ++jn)
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[i][jn][v] = 0.f;
 
@@ -127,17 +131,17 @@ patch_embed_gemm(const float* __restrict__ x, const float* __restrict__ w, const
     if (kt + 1 < KT) load_tile(kt + 1);
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss) {
-      f32x4 af[2], bf[2];
+      f32x4 af[TI], bf[TJ];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const f32x4*>(&As[buf][wm + i * 32 + r32][ss * 8 + half * 4]);
+      for (int i = 0; i < TI; ++i) af[i] = *reinterpret_cast<const f32x4*>(&As[buf][wm + i * 32 + r32][ss * 8 + half * 4]);
 #pragma unroll
-      for (int jn = 0; jn < 2; ++jn) bf[jn] = *reinterpret_cast<const f32x4*>(&Bs[buf][wn + jn * 32 + r32][ss * 8 + half * 4]);
+      for (int jn = 0; jn < TJ; ++jn) bf[jn] = *reinterpret_cast<const f32x4*>(&Bs[buf][wn + jn * 32 + r32][ss * 8 + half * 4]);
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
-          for (int jn = 0; jn < 2; ++jn) {
+          for (int jn = 0; jn < TJ; ++jn) {
             if constexpr (NHWC) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[jn][t], acc[i][jn], 0, 0, 0);
             else acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[jn][t], af[i][t], acc[i][jn], 0, 0, 0);
           }
@@ -148,9 +152,9 @@ patch_embed_gemm(const float* __restrict__ x, const float* __restrict__ w, const
 
   // ---- epilogue: accumulator register v of lane l is element (row 8 (v / 4) + 4 (l / 32) + v % 4, column l % 32) ----
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
-    for (int jn = 0; jn < 2; ++jn) {
+    for (int jn = 0; jn < TJ; ++jn) {
       if constexpr (NHWC) {          // rows = patches, columns = channels: a lane row writes 32 consecutive channels
         const int n = n0 + wn + jn * 32 + r32;
         const float bv = (bias && n < g.E) ? bias[n] : 0.f;
@@ -172,15 +176,30 @@ patch_embed_gemm(const float* __restrict__ x, const float* __restrict__ w, const
     }
 }
 
+template <int KS, int BM, int BN>
+static int launch_tile(const float* x, const float* w, const float* bias, const Geom& g, int channels_last, float* out,
+                       hipStream_t stream) {
+  dim3 grid((unsigned)((g.Mtot + BM - 1) / BM), (unsigned)((g.E + BN - 1) / BN));
+  if (channels_last)
+    hipLaunchKernelGGL((patch_embed_gemm<KS, true, BM, BN>), grid, dim3(kThreads), 0, stream, x, w, bias, g, out);
+  else
+    hipLaunchKernelGGL((patch_embed_gemm<KS, false, BM, BN>), grid, dim3(kThreads), 0, stream, x, w, bias, g, out);
+  return (int)hipGetLastError();
+}
+
+// Tile choice (tools/patch_embed_bench.py, PATCH_EMBED_TILE=1..3 forces one): 128 x 128 unless the launch would not
+// even give every CU one workgroup (then 64 x 128), or K is so short that the kernel is bound by writing the output
+// (ConvNeXt stem, K = 48: 64 x 64 tiles, 47 us vs 69 us).
 template <int KS>
 static int launch(const float* x, const float* w, const float* bias, const Geom& g, int channels_last, float* out,
                   hipStream_t stream) {
-  dim3 grid((unsigned)((g.Mtot + BM - 1) / BM), (unsigned)((g.E + BN - 1) / BN));
-  if (channels_last)
-    hipLaunchKernelGGL((patch_embed_gemm<KS, true>), grid, dim3(kThreads), 0, stream, x, w, bias, g, out);
-  else
-    hipLaunchKernelGGL((patch_embed_gemm<KS, false>), grid, dim3(kThreads), 0, stream, x, w, bias, g, out);
-  return (int)hipGetLastError();
+  auto tiles = [&](int bm, int bn) { return (long long)((g.Mtot + bm - 1) / bm) * ((g.E + bn - 1) / bn); };
+  static const int forced = std::getenv("PATCH_EMBED_TILE") ? std::atoi(std::getenv("PATCH_EMBED_TILE")) : 0;
+  int cfg = g.K <= 64 ? 2 : (tiles(128, 128) >= 256 ? 0 : 1);
+  if (forced >= 1 && forced <= 3) cfg = forced - 1;
+  if (cfg == 0) return launch_tile<KS, 128, 128>(x, w, bias, g, channels_last, out, stream);
+  if (cfg == 1) return launch_tile<KS, 64, 128>(x, w, bias, g, channels_last, out, stream);
+  return launch_tile<KS, 64, 64>(x, w, bias, g, channels_last, out, stream);
 }
 
 }  // namespace patch_embed
@@ -203,8 +222,7 @@ int patch_embed_hip_f32(const float* x, const float* weight, const float* bias, 
   g.Hp = height / patch; g.Wp = width / patch;
   const long long M = (long long)batch * g.Hp * g.Wp;
   if (M == 0) return 0;
-  if (M >= (1ll << 31) || K >= (1ll << 31) || (M + 127) / 128 > 0x7fffffffll ||
-      (long long)(embed_dim + 127) / 128 > 65535)
+  if (M >= (1ll << 31) || K >= (1ll << 31) || (long long)(embed_dim + 63) / 64 > 65535)
     return dynmask_set_error(PATCH_EMBED_ERR_BAD_DIMS, "patch_embed: problem too large");
   if (!x || !weight || !out) return dynmask_set_error(PATCH_EMBED_ERR_NULL_POINTER, "patch_embed: null pointer argument");
   g.Mtot = (int)M; g.K = (int)K;
