@@ -13,7 +13,7 @@ def _names():
 
 def golden_names():
     """MSDeformAttn operator fixtures (tests/golden/make_golden.py)."""
-    return [n for n in _names() if not n.startswith(("matcher_", "dynmask_", "patch_"))]
+    return [n for n in _names() if not n.startswith(("matcher_", "dynmask_", "patch_", "maskhead_"))]
 
 
 def dynmask_names():
@@ -24,6 +24,11 @@ def dynmask_names():
 def patch_names():
     """Patch-embedding fixtures (tests/golden/make_patch_embed_golden.py)."""
     return [n for n in _names() if n.startswith("patch_")]
+
+
+def maskhead_names():
+    """Static mask head fixtures (tests/golden/make_maskhead_golden.py)."""
+    return [n for n in _names() if n.startswith("maskhead_")]
 
 
 def matcher_names():

@@ -222,3 +222,84 @@ def patch_embed_forward(x, weight, bias=None, channels_last=True):
     if rc != 0:
         _raise(rc)
     return out
+
+
+def conv3x3_supported(x, weight):
+    """True when include/conv3x3_hip.h has a kernel: fp32 GPU tensors, weight [cout, cin, 3, 3], 9 * cin % 16 == 0."""
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4
+            and weight.dim() == 4 and tuple(weight.shape[2:]) == (3, 3) and x.shape[1] == weight.shape[1]
+            and (9 * weight.shape[1]) % 16 == 0)
+
+
+def conv3x3_forward(x, weight, bias=None, relu=False, precision=0):
+    """3x3 convolution, stride 1, zero padding 1, + bias (+ ReLU) on the matrix cores: the
+    `F.relu(self.layN(x))` steps of MaskHeadSmallConv.forward (ddetrs_dn.py:991-1025).  NCHW in, NCHW out; forward
+    only (inference).  precision 0: exact fp32 MFMA; 1: split-bf16 products with fp32 accumulation (~2e-5 of the
+    output scale, see include/conv3x3_hip.h)."""
+    lib = _lib.load()
+    _check("x", x, x.device)
+    _check("weight", weight, x.device)
+    if bias is not None:
+        _check("bias", bias, x.device)
+    for name, t in (("x", x), ("weight", weight), ("bias", bias)):
+        if t is not None and t.dtype != torch.float32:
+            raise RuntimeError("%s must be float32" % name)
+    if x.dim() != 4 or weight.dim() != 4 or tuple(weight.shape[2:]) != (3, 3) or x.shape[1] != weight.shape[1]:
+        raise RuntimeError("conv3x3_forward: expected x [B, C, H, W] and weight [E, C, 3, 3]")
+    if bias is not None and bias.shape != (weight.shape[0],):
+        raise RuntimeError("conv3x3_forward: bias must be [E]")
+    B, C, H, W = x.shape
+    E = weight.shape[0]
+    out = torch.empty((B, E, H, W), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.conv3x3_hip_f32(x.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                 B, C, H, W, E, int(bool(relu)), int(precision), out.data_ptr(),
+                                 ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc != 0:
+        _raise(rc)
+    return out
+
+
+def conv3x3_pack_weight(weight):
+    """Split + re-order a [cout, cin, 3, 3] fp32 GPU weight once for conv3x3_packed_forward (cin % 16 == 0).
+    Returns an opaque uint8 tensor on the same device."""
+    lib = _lib.load()
+    _check("weight", weight, weight.device)
+    if weight.dtype != torch.float32 or weight.dim() != 4 or tuple(weight.shape[2:]) != (3, 3):
+        raise RuntimeError("conv3x3_pack_weight: expected a float32 [cout, cin, 3, 3] weight")
+    cout, cin = weight.shape[:2]
+    nbytes = lib.conv3x3_hip_packed_weight_bytes(cout, cin)
+    if nbytes == 0:
+        raise RuntimeError("conv3x3_pack_weight: cin must be a multiple of 16")
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+    with torch.cuda.device(weight.device):
+        rc = lib.conv3x3_hip_pack_weight_f32(weight.data_ptr(), cout, cin, packed.data_ptr(),
+                                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc != 0:
+        _raise(rc)
+    return packed
+
+
+def conv3x3_packed_forward(x, packed, cout, bias=None, relu=False):
+    """3x3 / padding 1 convolution + bias (+ ReLU) from weights prepared by conv3x3_pack_weight: split-bf16 products
+    with fp32 accumulation (~2e-5 of the output scale), halo-tiled (include/conv3x3_hip.h)."""
+    lib = _lib.load()
+    _check("x", x, x.device)
+    _check("packed", packed, x.device)
+    if bias is not None:
+        _check("bias", bias, x.device)
+        if bias.dtype != torch.float32 or bias.shape != (cout,):
+            raise RuntimeError("conv3x3_packed_forward: bias must be float32 [cout]")
+    if x.dtype != torch.float32 or x.dim() != 4:
+        raise RuntimeError("conv3x3_packed_forward: expected a float32 x [B, C, H, W]")
+    B, C, H, W = x.shape
+    if packed.dtype != torch.uint8 or packed.numel() != lib.conv3x3_hip_packed_weight_bytes(int(cout), C):
+        raise RuntimeError("conv3x3_packed_forward: `packed` does not belong to a [%d, %d, 3, 3] weight" % (cout, C))
+    out = torch.empty((B, int(cout), H, W), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.conv3x3_hip_packed_f32(x.data_ptr(), packed.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                        B, C, H, W, int(cout), int(bool(relu)), out.data_ptr(),
+                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc != 0:
+        _raise(rc)
+    return out

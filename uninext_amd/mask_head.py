@@ -105,3 +105,87 @@ def dynamic_mask_with_coords(mask_feats, reference_points, mask_head_params, num
     logits = dynamic_mask_logits(mask_feats, reference_points, mask_head_params, num_insts, mask_feat_stride, rel_coord)
     logits = aligned_bilinear(logits, int(mask_feat_stride / mask_out_stride))
     return logits.reshape(1, -1, logits.shape[-2], logits.shape[-1])
+
+
+# ------------------------------------------------------------------------------------------------
+# Static mask-feature branch: MaskHeadSmallConv (ddetrs_dn.py:923-1031; the same class in models/ddetrs.py:670)
+
+def _expand(tensor, length):
+    return tensor.unsqueeze(1).repeat(1, int(length), 1, 1, 1).flatten(0, 1)   # ddetrs_dn.py:1112-1113
+
+
+def _packed_weight(conv):
+    """Split-bf16 packed copy of conv.weight, cached on the module and rebuilt when the parameter changes."""
+    w = conv.weight
+    key = (w.data_ptr(), w._version, str(w.device))
+    cache = conv.__dict__.get("_msda_packed")
+    if cache is None or cache[0] != key:
+        cache = (key, _ext.conv3x3_pack_weight(w.detach().contiguous()))
+        conv.__dict__["_msda_packed"] = cache
+    return cache[1]
+
+
+def conv3x3_relu(x, conv, exact=False):
+    """`F.relu(conv(x))` for a 3x3 / padding 1 nn.Conv2d.  Inference on the GPU runs the HIP implicit-GEMM kernels of
+    include/conv3x3_hip.h: by default the split-bf16 path from cached packed weights (~2e-5 of the output scale, inside
+    the 1e-4 parity bound), with exact=True the exact-fp32 MFMA kernel.  PyTorch otherwise (training, CPU, other
+    dtypes or geometries)."""
+    needs_grad = torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad)
+    if (not needs_grad and tuple(conv.kernel_size) == (3, 3) and tuple(conv.padding) == (1, 1)
+            and tuple(conv.stride) == (1, 1) and tuple(conv.dilation) == (1, 1) and conv.groups == 1
+            and _ext.conv3x3_supported(x, conv.weight)):
+        if not exact and conv.weight.shape[1] % 16 == 0:
+            return _ext.conv3x3_packed_forward(x.contiguous(), _packed_weight(conv), conv.weight.shape[0], conv.bias, relu=True)
+        return _ext.conv3x3_forward(x.contiguous(), conv.weight.contiguous(), conv.bias, relu=True)
+    return F.relu(conv(x))
+
+
+class MaskHeadSmallConv(torch.nn.Module):
+    """Simple convolutional head, FPN-style up-sampling (ddetrs_dn.py:923-1031): same constructor arguments, same
+    parameter names (lay1..lay4, jia_dcn, adapter1..3), same initialisation, same forward; the five
+    `F.relu(self.layN(...))` steps go through conv3x3_relu.  `use_raft` is not covered (False in every shipped
+    config, uninext/config.py:178)."""
+
+    exact_fp32 = False   # True: exact-fp32 MFMA kernel instead of the split-bf16 path (slower than MIOpen, see DESIGN.md)
+
+    def __init__(self, dim, fpn_dims, context_dim, use_raft=False, up_rate=4):
+        super().__init__()
+        if use_raft:
+            raise NotImplementedError("MaskHeadSmallConv(use_raft=True) is not part of this path")
+        self.use_raft = False
+        self.out_stride = 2
+        self.up_rate = up_rate
+        inter_dims = [dim, context_dim, context_dim, context_dim, context_dim, context_dim]
+        self.lay1 = torch.nn.Conv2d(dim, dim // 4, 3, padding=1)
+        self.lay2 = torch.nn.Conv2d(dim // 4, dim // 32, 3, padding=1)
+        self.lay3 = torch.nn.Conv2d(inter_dims[1], inter_dims[2], 3, padding=1)
+        self.lay4 = torch.nn.Conv2d(inter_dims[2], inter_dims[3], 3, padding=1)
+        self.jia_dcn = torch.nn.Conv2d(inter_dims[3], inter_dims[4], 3, padding=1)
+        self.dim = dim
+        if fpn_dims is not None:
+            self.adapter1 = torch.nn.Conv2d(fpn_dims[0], inter_dims[1], 1)
+            self.adapter2 = torch.nn.Conv2d(fpn_dims[1], inter_dims[2], 1)
+            self.adapter3 = torch.nn.Conv2d(fpn_dims[2], inter_dims[3], 1)
+        for m in self.modules():
+            if isinstance(m, torch.nn.Conv2d):
+                torch.nn.init.kaiming_uniform_(m.weight, a=1)
+                torch.nn.init.constant_(m.bias, 0)
+
+    def _merge(self, skip, adapter, fpn, fused):
+        if fpn is not None:
+            cur = adapter(fpn)
+            if cur.size(0) != skip.size(0):
+                cur = _expand(cur, skip.size(0) // cur.size(0))
+            skip = (cur + skip) / 2
+        if fused is None:
+            return skip
+        return skip + F.interpolate(fused, size=skip.shape[-2:], mode="nearest")
+
+    def forward(self, x, fpns):
+        f = fpns if fpns is not None else (None, None, None)
+        e = self.exact_fp32
+        fused = conv3x3_relu(self._merge(x[-1], getattr(self, "adapter1", None), f[0], None), self.lay3, e)
+        fused = conv3x3_relu(self._merge(x[-2], getattr(self, "adapter2", None), f[1], fused), self.lay4, e)
+        fused_fpn = conv3x3_relu(self._merge(x[-3], getattr(self, "adapter3", None), f[2], fused), self.jia_dcn, e)
+        fused = conv3x3_relu(fused_fpn, self.lay1, e)
+        return conv3x3_relu(fused, self.lay2, e)
