@@ -549,12 +549,17 @@ int conv3x3_hip_packed_f32(const float* in, const void* packed, const float* bia
   const int cout_pad = conv3x3::cout_padded(cout);
   const uint32_t* pk = static_cast<const uint32_t*>(packed);
   hipStream_t st = (hipStream_t)stream;
-  if (cout > 64) {
+  // 128 output channels per workgroup unless that leaves CUs idle (small feature maps): then 64
+  static const int forced_tj = std::getenv("CONV3X3_TJ") ? std::atoi(std::getenv("CONV3X3_TJ")) : 0;
+  bool wide = cout > 64 && tiles * ((cout + 127) / 128) >= 512;
+  if (forced_tj == 1) wide = false;
+  if (forced_tj == 2) wide = cout > 64;
+  if (wide) {
     dim3 grid((unsigned)tiles, (unsigned)((cout + 127) / 128));
     if (relu) hipLaunchKernelGGL((conv3x3::conv3x3_packed<2, true>), grid, dim3(conv3x3::kThreads), 0, st, in, pk, bias, g, tiles_x, tiles_x * tiles_y, cout_pad, out);
     else hipLaunchKernelGGL((conv3x3::conv3x3_packed<2, false>), grid, dim3(conv3x3::kThreads), 0, st, in, pk, bias, g, tiles_x, tiles_x * tiles_y, cout_pad, out);
   } else {
-    dim3 grid((unsigned)tiles, 1u);
+    dim3 grid((unsigned)tiles, (unsigned)((cout + 63) / 64));
     if (relu) hipLaunchKernelGGL((conv3x3::conv3x3_packed<1, true>), grid, dim3(conv3x3::kThreads), 0, st, in, pk, bias, g, tiles_x, tiles_x * tiles_y, cout_pad, out);
     else hipLaunchKernelGGL((conv3x3::conv3x3_packed<1, false>), grid, dim3(conv3x3::kThreads), 0, st, in, pk, bias, g, tiles_x, tiles_x * tiles_y, cout_pad, out);
   }
