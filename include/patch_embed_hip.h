@@ -21,6 +21,8 @@
 #ifndef PATCH_EMBED_HIP_H_
 #define PATCH_EMBED_HIP_H_
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -38,6 +40,20 @@ extern "C" {
  */
 int patch_embed_hip_f32(const float* x, const float* weight, const float* bias, int batch, int in_chans, int height,
                         int width, int embed_dim, int patch, int channels_last, float* out, void* stream);
+
+/*
+ * Fast path for inference with fixed weights: split-bf16 products.  Every fp32 operand is split into two bf16 halves
+ * (x = hi + lo, 16 mantissa bits kept) and a product is hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32
+ * accumulation: ~2e-5 of the output scale (inside the 1e-4 parity bound of this path) at 3/16 of the matrix-pipe time
+ * of the exact kernel.  The weights are split and re-ordered ONCE by patch_embed_hip_pack_weight_f32 into a
+ * caller-owned device buffer of patch_embed_hip_packed_weight_bytes(...) bytes (0 = unsupported geometry: patch not
+ * in {2, 4, 8, 16} or in_chans * patch^2 not a multiple of 48); patch_embed_hip_packed_f32 then takes that buffer in
+ * place of `weight`.  Same argument meaning and layouts as patch_embed_hip_f32.
+ */
+size_t patch_embed_hip_packed_weight_bytes(int embed_dim, int in_chans, int patch);
+int patch_embed_hip_pack_weight_f32(const float* weight, int embed_dim, int in_chans, int patch, void* packed, void* stream);
+int patch_embed_hip_packed_f32(const float* x, const void* packed, const float* bias, int batch, int in_chans, int height,
+                               int width, int embed_dim, int patch, int channels_last, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -66,6 +66,18 @@ def test_layer_mirrors_reference_on_cpu():
     assert max_abs(out.detach().numpy(), g["out"]) < 1e-11
 
 
+def test_packed_weight_sizes_need_no_gpu():
+    from uninext_amd import _lib
+    lib = _lib.load()
+    assert lib.patch_embed_hip_packed_weight_bytes(1280, 3, 16) == (768 // 16) * 2 * 1280 * 16 * 2
+    assert lib.patch_embed_hip_packed_weight_bytes(192, 3, 4) == 3 * 2 * 256 * 16 * 2        # E padded to 256
+    assert lib.patch_embed_hip_packed_weight_bytes(64, 5, 4) == 0                             # K = 80
+    assert lib.patch_embed_hip_packed_weight_bytes(64, 3, 3) == 0
+    one = 16
+    assert lib.patch_embed_hip_packed_f32(one, one, None, 1, 5, 32, 32, 8, 4, 1, one, None) == -5
+    assert lib.patch_embed_hip_pack_weight_f32(None, 8, 3, 16, one, None) == -1
+
+
 def test_supported_predicate():
     from uninext_amd import ext
     x = torch.zeros(1, 3, 32, 32)

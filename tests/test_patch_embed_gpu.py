@@ -45,6 +45,38 @@ def test_fixture(name, dev):
     (2, 8, 16, 2, 9, 11),          # K = 32, tiny
 ])
 @pytest.mark.parametrize("channels_last", [True, False])
+def test_packed_vs_oracle(k, C, E, B, H, W, channels_last, dev):
+    """Split-bf16 path from packed weights (where the geometry has one): 1e-4 of the output scale."""
+    from oracle import patch_embed_oracle
+    from uninext_amd import ext
+    rng = np.random.default_rng(k * 1000 + E + 1)
+    x = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    w = (rng.standard_normal((E, C, k, k)) / np.sqrt(C * k * k)).astype(np.float32)
+    b = rng.standard_normal(E).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    if (C * k * k) % 48 != 0:
+        assert not ext.patch_embed_packed_supported(t(w))
+        with pytest.raises(RuntimeError, match="multiple of 48"):
+            ext.patch_embed_pack_weight(t(w))
+        return
+    packed = ext.patch_embed_pack_weight(t(w))
+    ref = patch_embed_oracle.forward(x, w, b, channels_last)
+    out = ext.patch_embed_packed_forward(t(x), packed, E, k, t(b), channels_last).cpu().numpy()
+    assert out.shape == ref.shape and max_abs(out, ref) < 1e-4 * max(1.0, float(np.abs(ref).max()))
+    out = ext.patch_embed_packed_forward(t(x), packed, E, k, None, channels_last).cpu().numpy()
+    assert max_abs(out, patch_embed_oracle.forward(x, w, None, channels_last)) < 1e-4 * max(1.0, float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("k,C,E,B,H,W", [
+    (16, 3, 1280, 1, 80, 112),
+    (16, 3, 130, 3, 161, 207),
+    (8, 3, 96, 2, 40, 72),         # K = 192
+    (4, 3, 192, 2, 100, 135),      # K = 48: one step
+    (4, 5, 64, 1, 64, 64),         # K = 80: no packed path
+    (2, 192, 384, 1, 50, 68),
+    (2, 12, 16, 2, 9, 11),         # K = 48, tiny
+])
+@pytest.mark.parametrize("channels_last", [True, False])
 def test_vs_oracle(k, C, E, B, H, W, channels_last, dev):
     from oracle import patch_embed_oracle
     rng = np.random.default_rng(k * 1000 + E)
@@ -96,8 +128,15 @@ def test_layer_and_stream(dev):
     pe = PatchEmbed(in_chans=3, embed_dim=96).to(dev)
     x = torch.randn(2, 3, 64, 96, device=dev)
     with torch.no_grad():
-        got = pe(x)
+        got = pe(x)                                   # split-bf16 from cached packed weights
         want = pe.proj(x).permute(0, 2, 3, 1)
+        pe.exact_fp32 = True
+        got_exact = pe(x)
+        pe.exact_fp32 = False
+        assert float((got_exact - want).abs().max()) < 1e-5
+        pe.proj.weight.mul_(2.0)                      # in-place update: the packed copy must be rebuilt
+        assert float((pe(x) - pe.proj(x).permute(0, 2, 3, 1)).abs().max()) < 2e-4
+        pe.proj.weight.mul_(0.5)
     assert got.is_contiguous() and float((got - want).abs().max()) < 1e-4
     loss = pe(x).sum()              # autograd recording: PyTorch route, has a backward
     loss.backward()

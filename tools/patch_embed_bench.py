@@ -61,13 +61,20 @@ def main():
             ref = ref.permute(0, 2, 3, 1) if cl else ref
             err = float((out - ref).abs().max()) / float(ref.abs().max())
             t_hip = timeit(lambda: ext.patch_embed_forward(x, w, b, channels_last=cl), args.reps)
+            t_split, err_s = float("nan"), float("nan")
+            if ext.patch_embed_packed_supported(w):
+                packed = ext.patch_embed_pack_weight(w)
+                o2 = ext.patch_embed_packed_forward(x, packed, E, k, b, cl)
+                err_s = float((o2 - ref).abs().max()) / float(ref.abs().max())
+                t_split = timeit(lambda: ext.patch_embed_packed_forward(x, packed, E, k, b, cl), args.reps)
             t_conv = timeit(lambda: torch.nn.functional.conv2d(x, w, b, stride=k), args.reps)
             t_conv_cl = timeit(lambda: torch.nn.functional.conv2d(x, w, b, stride=k).permute(0, 2, 3, 1).contiguous(),
                                args.reps) if cl else float("nan")
         tf = flop / t_hip * 1e-6
-        print("%-48s M=%6d N=%4d K=%4d  hip %7.1f us %6.1f TFLOP/s = %4.1f %% of fp32 MFMA peak | torch conv %7.1f us"
-              "%s | rel err vs torch %.1e" % (name, B * (H // k) * (W // k), E, C * k * k, t_hip, tf, 100 * tf / PEAK_TF,
-                                             t_conv, (" (+permute copy %7.1f us)" % t_conv_cl) if cl else "", err))
+        print("%-48s M=%6d N=%4d K=%4d  exact %7.1f us %6.1f TFLOP/s = %4.1f %% of fp32 MFMA peak (err %.0e) | split-bf16 %7.1f us "
+              "%6.1f TFLOP/s (err %.0e) | torch conv %7.1f us%s"
+              % (name, B * (H // k) * (W // k), E, C * k * k, t_hip, tf, 100 * tf / PEAK_TF, err, t_split,
+                 flop / t_split * 1e-6, err_s, t_conv, (" (+permute copy %7.1f us)" % t_conv_cl) if cl else ""))
 
 
 if __name__ == "__main__":

@@ -21,15 +21,37 @@ def _use_hip(x, conv):
             and ext.patch_embed_supported(x, conv.weight, conv.stride, conv.padding))
 
 
-def patch_conv2d(x, conv):
-    """`conv(x)` for an nn.Conv2d whose kernel equals its stride (no padding): [B, E, H // k, W // k]."""
+def _packed_weight(conv):
+    """Split-bf16 packed copy of conv.weight, cached on the module and rebuilt when the parameter changes."""
+    w = conv.weight
+    key = (w.data_ptr(), w._version, str(w.device))
+    cache = conv.__dict__.get("_msda_packed")
+    if cache is None or cache[0] != key:
+        cache = (key, ext.patch_embed_pack_weight(w.detach().contiguous()))
+        conv.__dict__["_msda_packed"] = cache
+    return cache[1]
+
+
+def _hip_conv(x, conv, channels_last, exact):
+    w = conv.weight
+    # short K (ConvNeXt stem, K = 48): the kernel is bound by writing the output and the exact one is faster
+    if not exact and w.shape[1] * w.shape[2] * w.shape[3] > 64 and ext.patch_embed_packed_supported(w):
+        return ext.patch_embed_packed_forward(x, _packed_weight(conv), w.shape[0], w.shape[2], conv.bias, channels_last)
+    return ext.patch_embed_forward(x, w.contiguous(), conv.bias, channels_last=channels_last)
+
+
+def patch_conv2d(x, conv, exact=False):
+    """`conv(x)` for an nn.Conv2d whose kernel equals its stride (no padding): [B, E, H // k, W // k].  Inference on
+    the GPU: split-bf16 products from cached packed weights (~2e-5 of the output scale; exact=True: exact-fp32 MFMA)."""
     if _use_hip(x, conv):
-        return ext.patch_embed_forward(x, conv.weight.contiguous(), conv.bias, channels_last=False)
+        return _hip_conv(x, conv, False, exact)
     return conv(x)
 
 
 class PatchEmbed(nn.Module):
     """Image to Patch Embedding (backbone/utils.py:160-186): same constructor, same `proj` parameter names."""
+
+    exact_fp32 = False   # True: exact-fp32 MFMA kernel instead of the split-bf16 path
 
     def __init__(self, kernel_size=(16, 16), stride=(16, 16), padding=(0, 0), in_chans=3, embed_dim=768):
         super().__init__()
@@ -37,6 +59,6 @@ class PatchEmbed(nn.Module):
 
     def forward(self, x):
         if _use_hip(x, self.proj):
-            return ext.patch_embed_forward(x, self.proj.weight.contiguous(), self.proj.bias, channels_last=True)
+            return _hip_conv(x, self.proj, True, self.exact_fp32)
         x = self.proj(x)
         return x.permute(0, 2, 3, 1)   # B C H W -> B H W C (a view, as in the reference)

@@ -176,6 +176,200 @@ patch_embed_gemm(const float* __restrict__ x, const float* __restrict__ w, const
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// patch_embed_packed<KS, NHWC, TJ>: split-bf16 products (see conv3x3.hip / include/patch_embed_hip.h) from weights that
+// were split and re-ordered once into [K / 16 chunks][hi, lo][E padded][16 k] bf16.  A tile = 128 patches x 48 k per
+// step (three 16-k chunks), staged through double-buffered LDS as [chunk][patch][16 bf16] hi / lo (one ds_read_b128
+// per MFMA operand); a wave's weight fragment of a chunk is 1 KB of contiguous memory loaded straight into registers
+// two chunks ahead (ring of three register sets).  36 v_mfma_f32_32x32x16_bf16 per wave and barrier (TJ = 2).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4v __attribute__((__vector_size__(16)));
+constexpr int kChunk = 16, kStepChunks = 3, kStepK = kChunk * kStepChunks;   // 48 k per barrier
+
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4v& hi, u32x4v& lo) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const uint32_t a = __float_as_uint(v[2 * p]), b = __float_as_uint(v[2 * p + 1]);
+    const uint32_t ah = a & 0xffff0000u, bh = b & 0xffff0000u;
+    const uint32_t al = __float_as_uint(v[2 * p] - __uint_as_float(ah));
+    const uint32_t bl = __float_as_uint(v[2 * p + 1] - __uint_as_float(bh));
+    hi[p] = (ah >> 16) | bh;
+    lo[p] = (al >> 16) | (bl & 0xffff0000u);
+  }
+}
+
+template <int KS, bool NHWC, int TJ>
+__global__ void __launch_bounds__(kThreads, 2)
+patch_embed_packed(const float* __restrict__ x, const uint32_t* __restrict__ packed, const float* __restrict__ bias, Geom g,
+                   int e_pad, float* __restrict__ out) {
+  constexpr int BM = 128;
+  constexpr int VW = KS >= 4 ? 4 : 2;
+  __shared__ __attribute__((aligned(16))) uint32_t As[2][2][kStepChunks][BM][8];   // [buffer][hi / lo][chunk][patch][16 bf16]
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * (64 * TJ);
+  const int HpWp = g.Hp * g.Wp;
+
+  // staging items: (chunk of the step, patch row, half = 8 consecutive k); this thread owns item tid of every chunk
+  const int s_row = tid & 127, s_half = tid >> 7;
+  int64_t a_base;
+  {
+    int m = m0 + s_row;
+    m = m < g.Mtot ? m : g.Mtot - 1;
+    const int b = m / HpWp, sp = m - b * HpWp;
+    const int py = sp / g.Wp, px = sp - py * g.Wp;
+    a_base = ((int64_t)b * g.C * g.H + (int64_t)py * KS) * g.W + (int64_t)px * KS;
+  }
+  float a_reg[kStepChunks][8];
+  auto load_step = [&](int st) {
+#pragma unroll
+    for (int cc = 0; cc < kStepChunks; ++cc)
+#pragma unroll
+      for (int j = 0; j < 8 / VW; ++j) {
+        const int kk = st * kStepK + cc * kChunk + s_half * 8 + j * VW;   // (c * KS + ky) * KS + kx, kx multiple of VW
+        const int c = kk / (KS * KS), r = kk % (KS * KS);
+        const int ky = r / KS, kx = r % KS;
+        const float* p = x + a_base + ((int64_t)c * g.H + ky) * g.W + kx;
+#pragma unroll
+        for (int e = 0; e < VW; ++e) a_reg[cc][j * VW + e] = p[e];
+      }
+  };
+  auto store_step = [&](int buf) {
+#pragma unroll
+    for (int cc = 0; cc < kStepChunks; ++cc) {
+      u32x4v hi, lo;
+      split8(a_reg[cc], hi, lo);
+      *reinterpret_cast<u32x4v*>(&As[buf][0][cc][s_row][s_half * 4]) = hi;
+      *reinterpret_cast<u32x4v*>(&As[buf][1][cc][s_row][s_half * 4]) = lo;
+    }
+  };
+
+  const int wm = (wv >> 1) * 64, wn = (wv & 1) * 32 * TJ;
+  const int r32 = lane & 31, half = lane >> 5;
+  const int nb = n0 + wn + r32;
+  const uint32_t* w_lane = packed + (int64_t)nb * 8 + half * 4;
+  const int64_t chunk_stride = (int64_t)2 * e_pad * 8, part_stride = (int64_t)e_pad * 8;
+  const int nchunks = g.K / kChunk, nsteps = g.K / kStepK;
+  struct WFrag { u32x4v hi[TJ], lo[TJ]; };
+  auto load_w = [&](int ch, WFrag& f) {
+    const int cc = ch < nchunks ? ch : nchunks - 1;
+    const uint32_t* p = w_lane + cc * chunk_stride;
+#pragma unroll
+    for (int jn = 0; jn < TJ; ++jn) {
+      f.hi[jn] = *reinterpret_cast<const u32x4v*>(p + jn * 32 * 8);
+      f.lo[jn] = *reinterpret_cast<const u32x4v*>(p + part_stride + jn * 32 * 8);
+    }
+  };
+
+  f32x16 acc[2][TJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jn = 0; jn < TJ; ++jn)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][jn][v] = 0.f;
+
+  auto chunk_mfma = [&](int buf, int cc, const WFrag& wf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(&As[buf][0][cc][wm + i * 32 + r32][half * 4]));
+      const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(&As[buf][1][cc][wm + i * 32 + r32][half * 4]));
+#pragma unroll
+      for (int jn = 0; jn < TJ; ++jn) {
+        const bf16x8 wh = __builtin_bit_cast(bf16x8, wf.hi[jn]), wl = __builtin_bit_cast(bf16x8, wf.lo[jn]);
+        if constexpr (NHWC) {
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl, acc[i][jn], 0, 0, 0);
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh, acc[i][jn], 0, 0, 0);
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc[i][jn], 0, 0, 0);
+        } else {
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, ah, acc[i][jn], 0, 0, 0);
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, al, acc[i][jn], 0, 0, 0);
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ah, acc[i][jn], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  WFrag w0, w1, w2;
+  load_step(0);
+  load_w(0, w0);
+  load_w(1, w1);
+  store_step(0);
+  __syncthreads();
+  for (int st = 0; st < nsteps; ++st) {
+    const int buf = st & 1, ch = st * kStepChunks;
+    if (st + 1 < nsteps) load_step(st + 1);
+    load_w(ch + 2, w2);
+    chunk_mfma(buf, 0, w0);
+    load_w(ch + 3, w0);
+    chunk_mfma(buf, 1, w1);
+    load_w(ch + 4, w1);
+    chunk_mfma(buf, 2, w2);
+    if (st + 1 < nsteps) store_step(buf ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jn = 0; jn < TJ; ++jn) {
+      if constexpr (NHWC) {
+        const int n = n0 + wn + jn * 32 + r32;
+        const float bv = (bias && n < g.E) ? bias[n] : 0.f;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int m = m0 + wm + i * 32 + 8 * (v / 4) + 4 * half + (v % 4);
+          if (m < g.Mtot && n < g.E) out[(int64_t)m * g.E + n] = acc[i][jn][v] + bv;
+        }
+      } else {
+        const int m = m0 + wm + i * 32 + r32;
+        const int b = m / HpWp, sp = m - b * HpWp;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int n = n0 + wn + jn * 32 + 8 * (v / 4) + 4 * half + (v % 4);
+          if (m < g.Mtot && n < g.E)
+            out[((int64_t)b * g.E + n) * HpWp + sp] = acc[i][jn][v] + (bias ? bias[n] : 0.f);
+        }
+      }
+    }
+}
+
+// weight [E, K] fp32 (K = C * patch^2 contiguous) -> packed [K / 16][hi, lo][e_pad][16] bf16
+__global__ void pack_weight_kernel(const float* __restrict__ w, int E, int K, int e_pad, uint16_t* __restrict__ packed) {
+  const int64_t total = (int64_t)(K / kChunk) * e_pad * kChunk;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int kl = (int)(idx % kChunk);
+    const int n = (int)((idx / kChunk) % e_pad);
+    const int chunk = (int)(idx / kChunk / e_pad);
+    const float v = n < E ? w[(int64_t)n * K + chunk * kChunk + kl] : 0.f;
+    const uint32_t bits = __float_as_uint(v), hb = bits & 0xffff0000u;
+    const uint32_t lb = __float_as_uint(v - __uint_as_float(hb));
+    const int64_t o = ((int64_t)chunk * 2 * e_pad + n) * kChunk + kl;
+    packed[o] = (uint16_t)(hb >> 16);
+    packed[o + (int64_t)e_pad * kChunk] = (uint16_t)(lb >> 16);
+  }
+}
+
+static inline int e_padded(int E) { return (E + 127) / 128 * 128; }
+
+template <int KS>
+static int launch_packed(const float* x, const uint32_t* packed, const float* bias, const Geom& g, int channels_last,
+                         float* out, hipStream_t stream) {
+  const int e_pad = e_padded(g.E);
+  const long long mt = (g.Mtot + 127) / 128;
+  const bool wide = g.E > 64 && mt * ((g.E + 127) / 128) >= 512;   // 128 channels per workgroup unless CUs would idle
+  if (wide) {
+    dim3 grid((unsigned)mt, (unsigned)((g.E + 127) / 128));
+    if (channels_last) hipLaunchKernelGGL((patch_embed_packed<KS, true, 2>), grid, dim3(kThreads), 0, stream, x, packed, bias, g, e_pad, out);
+    else hipLaunchKernelGGL((patch_embed_packed<KS, false, 2>), grid, dim3(kThreads), 0, stream, x, packed, bias, g, e_pad, out);
+  } else {
+    dim3 grid((unsigned)mt, (unsigned)((g.E + 63) / 64));
+    if (channels_last) hipLaunchKernelGGL((patch_embed_packed<KS, true, 1>), grid, dim3(kThreads), 0, stream, x, packed, bias, g, e_pad, out);
+    else hipLaunchKernelGGL((patch_embed_packed<KS, false, 1>), grid, dim3(kThreads), 0, stream, x, packed, bias, g, e_pad, out);
+  }
+  return (int)hipGetLastError();
+}
+
 template <int KS, int BM, int BN>
 static int launch_tile(const float* x, const float* w, const float* bias, const Geom& g, int channels_last, float* out,
                        hipStream_t stream) {
@@ -232,6 +426,51 @@ int patch_embed_hip_f32(const float* x, const float* weight, const float* bias, 
     case 4: rc = patch_embed::launch<4>(x, weight, bias, g, channels_last, out, (hipStream_t)stream); break;
     case 8: rc = patch_embed::launch<8>(x, weight, bias, g, channels_last, out, (hipStream_t)stream); break;
     default: rc = patch_embed::launch<16>(x, weight, bias, g, channels_last, out, (hipStream_t)stream); break;
+  }
+  return rc == 0 ? 0 : dynmask_set_error(rc, hipGetErrorString((hipError_t)rc));
+}
+
+
+size_t patch_embed_hip_packed_weight_bytes(int embed_dim, int in_chans, int patch) {
+  const long long K = (long long)in_chans * patch * patch;
+  if (embed_dim <= 0 || in_chans <= 0 || (patch != 2 && patch != 4 && patch != 8 && patch != 16) ||
+      K % patch_embed::kStepK != 0)
+    return 0;
+  return (size_t)(K / patch_embed::kChunk) * 2 * patch_embed::e_padded(embed_dim) * patch_embed::kChunk * sizeof(uint16_t);
+}
+
+int patch_embed_hip_pack_weight_f32(const float* weight, int embed_dim, int in_chans, int patch, void* packed, void* stream) {
+  if (patch_embed_hip_packed_weight_bytes(embed_dim, in_chans, patch) == 0)
+    return dynmask_set_error(PATCH_EMBED_ERR_UNSUPPORTED, "patch_embed: packed weights need patch in {2,4,8,16} and C * patch^2 a multiple of 48");
+  if (!weight || !packed) return dynmask_set_error(PATCH_EMBED_ERR_NULL_POINTER, "patch_embed: null pointer argument");
+  hipLaunchKernelGGL(patch_embed::pack_weight_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, weight, embed_dim,
+                     in_chans * patch * patch, patch_embed::e_padded(embed_dim), static_cast<uint16_t*>(packed));
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : dynmask_set_error((int)e, hipGetErrorString(e));
+}
+
+int patch_embed_hip_packed_f32(const float* x, const void* packed, const float* bias, int batch, int in_chans, int height,
+                               int width, int embed_dim, int patch, int channels_last, float* out, void* stream) {
+  if (batch < 0 || in_chans <= 0 || height <= 0 || width <= 0 || embed_dim <= 0 || patch <= 0)
+    return dynmask_set_error(PATCH_EMBED_ERR_BAD_DIMS, "patch_embed: bad dimensions");
+  if (patch_embed_hip_packed_weight_bytes(embed_dim, in_chans, patch) == 0)
+    return dynmask_set_error(PATCH_EMBED_ERR_UNSUPPORTED, "patch_embed: packed weights need patch in {2,4,8,16} and C * patch^2 a multiple of 48");
+  patch_embed::Geom g;
+  g.B = batch; g.C = in_chans; g.H = height; g.W = width; g.E = embed_dim;
+  g.Hp = height / patch; g.Wp = width / patch;
+  const long long M = (long long)batch * g.Hp * g.Wp, K = (long long)in_chans * patch * patch;
+  if (M == 0) return 0;
+  if (M >= (1ll << 31) || K >= (1ll << 31) || (long long)(embed_dim + 63) / 64 > 65535)
+    return dynmask_set_error(PATCH_EMBED_ERR_BAD_DIMS, "patch_embed: problem too large");
+  if (!x || !packed || !out) return dynmask_set_error(PATCH_EMBED_ERR_NULL_POINTER, "patch_embed: null pointer argument");
+  g.Mtot = (int)M; g.K = (int)K;
+  const uint32_t* pk = static_cast<const uint32_t*>(packed);
+  int rc;
+  switch (patch) {
+    case 2: rc = patch_embed::launch_packed<2>(x, pk, bias, g, channels_last, out, (hipStream_t)stream); break;
+    case 4: rc = patch_embed::launch_packed<4>(x, pk, bias, g, channels_last, out, (hipStream_t)stream); break;
+    case 8: rc = patch_embed::launch_packed<8>(x, pk, bias, g, channels_last, out, (hipStream_t)stream); break;
+    default: rc = patch_embed::launch_packed<16>(x, pk, bias, g, channels_last, out, (hipStream_t)stream); break;
   }
   return rc == 0 ? 0 : dynmask_set_error(rc, hipGetErrorString((hipError_t)rc));
 }

@@ -303,3 +303,55 @@ def conv3x3_packed_forward(x, packed, cout, bias=None, relu=False):
     if rc != 0:
         _raise(rc)
     return out
+
+
+def patch_embed_packed_supported(weight):
+    """True when the split-bf16 packed path of include/patch_embed_hip.h covers this [E, C, k, k] weight."""
+    return (weight.dim() == 4 and weight.shape[2] == weight.shape[3] and
+            _lib.load().patch_embed_hip_packed_weight_bytes(weight.shape[0], weight.shape[1], weight.shape[2]) > 0)
+
+
+def patch_embed_pack_weight(weight):
+    """Split + re-order an [E, C, k, k] fp32 GPU weight once for patch_embed_packed_forward.  Opaque uint8 tensor."""
+    lib = _lib.load()
+    _check("weight", weight, weight.device)
+    if weight.dtype != torch.float32 or weight.dim() != 4 or weight.shape[2] != weight.shape[3]:
+        raise RuntimeError("patch_embed_pack_weight: expected a float32 [E, C, k, k] weight")
+    E, C, k = weight.shape[0], weight.shape[1], weight.shape[2]
+    nbytes = lib.patch_embed_hip_packed_weight_bytes(E, C, k)
+    if nbytes == 0:
+        raise RuntimeError("patch_embed_pack_weight: needs k in {2, 4, 8, 16} and C * k * k a multiple of 48")
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+    with torch.cuda.device(weight.device):
+        rc = lib.patch_embed_hip_pack_weight_f32(weight.data_ptr(), E, C, k, packed.data_ptr(),
+                                                 ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc != 0:
+        _raise(rc)
+    return packed
+
+
+def patch_embed_packed_forward(x, packed, embed_dim, patch, bias=None, channels_last=True):
+    """patch_embed_forward with split-bf16 products (~2e-5 of the output scale) from weights prepared by
+    patch_embed_pack_weight."""
+    lib = _lib.load()
+    _check("x", x, x.device)
+    _check("packed", packed, x.device)
+    if x.dtype != torch.float32 or x.dim() != 4:
+        raise RuntimeError("patch_embed_packed_forward: expected a float32 x [B, C, H, W]")
+    B, C, H, W = x.shape
+    E, k = int(embed_dim), int(patch)
+    if bias is not None:
+        _check("bias", bias, x.device)
+        if bias.dtype != torch.float32 or bias.shape != (E,):
+            raise RuntimeError("patch_embed_packed_forward: bias must be float32 [E]")
+    if packed.dtype != torch.uint8 or packed.numel() == 0 or packed.numel() != lib.patch_embed_hip_packed_weight_bytes(E, C, k):
+        raise RuntimeError("patch_embed_packed_forward: `packed` does not belong to a [%d, %d, %d, %d] weight" % (E, C, k, k))
+    shape = (B, H // k, W // k, E) if channels_last else (B, E, H // k, W // k)
+    out = torch.empty(shape, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.patch_embed_hip_packed_f32(x.data_ptr(), packed.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                            B, C, H, W, E, k, int(bool(channels_last)), out.data_ptr(),
+                                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc != 0:
+        _raise(rc)
+    return out
