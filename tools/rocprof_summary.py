@@ -34,9 +34,20 @@ def pmc(dbs):
                          "avg(value), min(value), max(value) from counters_collection "
                          "group by kernel_name, grid_size_x, grid_size_y, counter_name order by avg(value) desc").fetchall()
         print("%-58s %-14s %-14s %6s %14s %14s %14s" % ("kernel", "grid(x,y)/wg", "counter", "calls", "avg", "min", "max"))
-        for n, gx, gy, wx, cn, cnt, avg, mn, mx in rows[:12]:
+        for n, gx, gy, wx, cn, cnt, avg, mn, mx in rows[:60]:
             print("%-58s %-14s %-14s %6d %14.1f %14.1f %14.1f" % (short(n)[:58], "%dx%d/%d" % (gx // max(wx, 1), gy, wx),
                                                                 cn, cnt, avg, mn, mx))
+        # matrix-pipe utilisation where the counters are there: MFMA-busy cycles summed over the 1024 SIMDs /
+        # (GRBM_GUI_ACTIVE summed over the 8 XCDs / 8 * 1024)  -- rocprofv3's MfmaUtil, per kernel
+        vals = {}
+        for n, gx, gy, wx, cn, cnt, avg, mn, mx in rows:
+            vals.setdefault((short(n), gx, gy, wx), {})[cn] = avg
+        for (n, gx, gy, wx), v in vals.items():
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v and v["GRBM_GUI_ACTIVE"] > 0:
+                print("MfmaUtil %-50s %-14s %5.1f %%   (%.0f busy cycles per SIMD of %.0f)" % (
+                    n[:50], "%dx%d/%d" % (gx // max(wx, 1), gy, wx),
+                    100.0 * v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0),
+                    v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0, v["GRBM_GUI_ACTIVE"] / 8.0))
 
 
 if __name__ == "__main__":
