@@ -1,0 +1,44 @@
+/*
+ * include/linear_hip.h -- C ABI of the fp32 Linear layers around the MSDeformAttn operator on MI355X (gfx950), part
+ * of libmsda_hip.so.
+ *
+ * MSDeformAttn.forward (projects/UNINEXT/uninext/models/deformable_detr/ops/modules/ms_deform_attn.py:95-116) runs
+ * four nn.Linear layers around the sampling kernel: value_proj (+ masked_fill of padded tokens, :95-97),
+ * sampling_offsets (:99), attention_weights (:100) and output_proj (:114); at the R50 shapes (44 446 tokens x 256)
+ * they take 2/3 of the layer's time.  These entry points compute
+ *     out[m, n] = (row_mask && row_mask[m]) ? 0 : bias[n] + sum_k x[m, k] * weight[n, k]
+ * with split-bf16 products on the matrix cores: every fp32 operand is split into two bf16 halves (x = hi + lo, 16
+ * mantissa bits kept) and a product is hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation --
+ * ~2e-5 of the output scale, inside the 1e-4 parity bound of the path.  The weight is split and re-ordered ONCE
+ * (linear_hip_pack_weight_f32) into a caller-owned device buffer of linear_hip_packed_weight_bytes(n, k) bytes.
+ *
+ * All pointers are device pointers, contiguous, row-major; `bias` and `row_mask` (one byte per row, non-zero = write
+ * zeros: the reference's masked_fill(input_padding_mask[..., None], 0)) may be NULL; `stream` is a hipStream_t as
+ * void*; kernels are only enqueued.  in_features must be a multiple of 64.  Returns 0, a negative LINEAR_ERR_*, or a
+ * positive hipError_t; the message is available from msda_hip_last_error().
+ */
+#ifndef LINEAR_HIP_H_
+#define LINEAR_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LINEAR_ERR_NULL_POINTER (-1)
+#define LINEAR_ERR_BAD_DIMS (-2)
+#define LINEAR_ERR_UNSUPPORTED (-5)   /* in_features not a multiple of 64 */
+
+size_t linear_hip_packed_weight_bytes(int out_features, int in_features);   /* 0 if unsupported */
+/* weight [out_features, in_features] fp32 (nn.Linear layout) -> packed */
+int linear_hip_pack_weight_f32(const float* weight, int out_features, int in_features, void* packed, void* stream);
+/* x [rows, in_features] -> out [rows, out_features] */
+int linear_hip_packed_f32(const float* x, const void* packed, const float* bias, const uint8_t* row_mask,
+                          long long rows, int in_features, int out_features, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LINEAR_HIP_H_ */

@@ -18,6 +18,7 @@ EXPORTS = (
 DYNMASK_EXPORTS = ("dynmask_hip_forward_f32", "aligned_bilinear_hip_f32")   # include/dynmask_hip.h
 PATCH_EMBED_EXPORTS = ("patch_embed_hip_f32", "patch_embed_hip_packed_weight_bytes", "patch_embed_hip_pack_weight_f32",
                        "patch_embed_hip_packed_f32")                           # include/patch_embed_hip.h
+LINEAR_EXPORTS = ("linear_hip_packed_weight_bytes", "linear_hip_pack_weight_f32", "linear_hip_packed_f32")  # include/linear_hip.h
 CONV3X3_EXPORTS = ("conv3x3_hip_f32", "conv3x3_hip_packed_weight_bytes", "conv3x3_hip_pack_weight_f32",
                    "conv3x3_hip_packed_f32")                                   # include/conv3x3_hip.h
 
@@ -53,6 +54,10 @@ def load():
     lib.patch_embed_hip_packed_weight_bytes.restype = ctypes.c_size_t
     lib.patch_embed_hip_pack_weight_f32.argtypes, lib.patch_embed_hip_pack_weight_f32.restype = [p, i, i, i, p, p], i
     lib.patch_embed_hip_packed_f32.argtypes, lib.patch_embed_hip_packed_f32.restype = [p, p, p, i, i, i, i, i, i, i, p, p], i
+    lib.linear_hip_packed_weight_bytes.argtypes, lib.linear_hip_packed_weight_bytes.restype = [i, i], ctypes.c_size_t
+    lib.linear_hip_pack_weight_f32.argtypes, lib.linear_hip_pack_weight_f32.restype = [p, i, i, p, p], i
+    lib.linear_hip_packed_f32.argtypes = [p, p, p, p, ctypes.c_longlong, i, i, p, p]
+    lib.linear_hip_packed_f32.restype = i
     lib.conv3x3_hip_f32.argtypes, lib.conv3x3_hip_f32.restype = [p, p, p, i, i, i, i, i, i, i, p, p], i
     lib.conv3x3_hip_packed_weight_bytes.argtypes, lib.conv3x3_hip_packed_weight_bytes.restype = [i, i], ctypes.c_size_t
     lib.conv3x3_hip_pack_weight_f32.argtypes, lib.conv3x3_hip_pack_weight_f32.restype = [p, i, i, p, p], i

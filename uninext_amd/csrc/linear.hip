@@ -1,0 +1,231 @@
+// fp32 Linear layers with split-bf16 products on the gfx950 matrix cores -- see include/linear_hip.h.
+//
+//   out[m, n] = bias[n] + sum_k x[m, k] * W[n, k]
+//
+// Same scheme as conv3x3_packed / patch_embed_packed: W is split (hi = upper 16 bits, lo = bf16 of the remainder)
+// and re-ordered once into [K / 16 chunks][hi, lo][N padded to 128][16 k] bf16, so a wave's weight fragment of a
+// chunk is 1 KB of contiguous memory loaded straight into registers (ring of four register sets, three chunks
+// ahead); the activation tile (128 rows x 64 k per step) is split while it is staged into double-buffered LDS as
+// [chunk][row][16 bf16] hi / lo, one ds_read_b128 per MFMA operand.  Workgroup: 256 threads = 2 x 2 waves, 128 rows
+// x 64 TJ columns; per step a wave issues 12 TJ x 2 v_mfma_f32_32x32x16_bf16.  At K = 256 (the only size the layer
+// uses) a tile is 4 steps: the kernel is bound by reading x and writing out, not by the matrix pipe.
+#include "../../include/linear_hip.h"
+
+#include "msda_common.hpp"
+
+namespace linear {
+
+typedef float f32x16 __attribute__((__vector_size__(64)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4v __attribute__((__vector_size__(16)));
+using msda::f32x4;
+
+constexpr int kThreads = 256, BM = 128;
+constexpr int kChunk = 16, kStepChunks = 4, kStepK = kChunk * kStepChunks;   // 64 k per barrier
+
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4v& hi, u32x4v& lo) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const uint32_t a = __float_as_uint(v[2 * p]), b = __float_as_uint(v[2 * p + 1]);
+    const uint32_t ah = a & 0xffff0000u, bh = b & 0xffff0000u;
+    const uint32_t al = __float_as_uint(v[2 * p] - __uint_as_float(ah));
+    const uint32_t bl = __float_as_uint(v[2 * p + 1] - __uint_as_float(bh));
+    hi[p] = (ah >> 16) | bh;
+    lo[p] = (al >> 16) | (bl & 0xffff0000u);
+  }
+}
+
+template <int TJ>
+__global__ void __launch_bounds__(kThreads, 2)
+linear_packed(const float* __restrict__ x, const uint32_t* __restrict__ packed, const float* __restrict__ bias,
+              const uint8_t* __restrict__ row_mask, long long M, int K, int N, int n_pad, float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) uint32_t As[2][2][kStepChunks][BM][8];   // [buffer][hi / lo][chunk][row][16 bf16]
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const long long m0 = (long long)blockIdx.x * BM;
+  const int n0 = blockIdx.y * (64 * TJ);
+
+  // staging: this thread owns (row tid % 128, k half tid / 128) of every chunk of a step: 8 consecutive floats
+  const int s_row = tid & 127, s_half = tid >> 7;
+  long long mr = m0 + s_row;
+  mr = mr < M ? mr : M - 1;
+  const float* a_ptr = x + mr * K + s_half * 8;
+  f32x4 a_reg[kStepChunks][2];
+  auto load_step = [&](int st) {
+#pragma unroll
+    for (int cc = 0; cc < kStepChunks; ++cc) {
+      const float* p = a_ptr + st * kStepK + cc * kChunk;
+      a_reg[cc][0] = *reinterpret_cast<const f32x4*>(p);
+      a_reg[cc][1] = *reinterpret_cast<const f32x4*>(p + 4);
+    }
+  };
+  auto store_step = [&](int buf) {
+#pragma unroll
+    for (int cc = 0; cc < kStepChunks; ++cc) {
+      const float v[8] = {a_reg[cc][0][0], a_reg[cc][0][1], a_reg[cc][0][2], a_reg[cc][0][3],
+                          a_reg[cc][1][0], a_reg[cc][1][1], a_reg[cc][1][2], a_reg[cc][1][3]};
+      u32x4v hi, lo;
+      split8(v, hi, lo);
+      *reinterpret_cast<u32x4v*>(&As[buf][0][cc][s_row][s_half * 4]) = hi;
+      *reinterpret_cast<u32x4v*>(&As[buf][1][cc][s_row][s_half * 4]) = lo;
+    }
+  };
+
+  const int wm = (wv >> 1) * 64, wn = (wv & 1) * 32 * TJ;
+  const int r32 = lane & 31, half = lane >> 5;
+  const uint32_t* w_lane = packed + (long long)(n0 + wn + r32) * 8 + half * 4;
+  const long long chunk_stride = (long long)2 * n_pad * 8, part_stride = (long long)n_pad * 8;
+  const int nchunks = K / kChunk, nsteps = K / kStepK;
+  struct WFrag { u32x4v hi[TJ], lo[TJ]; };
+  auto load_w = [&](int ch, WFrag& f) {
+    const int cc = ch < nchunks ? ch : nchunks - 1;
+    const uint32_t* p = w_lane + cc * chunk_stride;
+#pragma unroll
+    for (int jn = 0; jn < TJ; ++jn) {
+      f.hi[jn] = *reinterpret_cast<const u32x4v*>(p + jn * 32 * 8);
+      f.lo[jn] = *reinterpret_cast<const u32x4v*>(p + part_stride + jn * 32 * 8);
+    }
+  };
+
+  f32x16 acc[2][TJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jn = 0; jn < TJ; ++jn)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][jn][v] = 0.f;
+
+  auto chunk_mfma = [&](int buf, int cc, const WFrag& wf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(&As[buf][0][cc][wm + i * 32 + r32][half * 4]));
+      const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(&As[buf][1][cc][wm + i * 32 + r32][half * 4]));
+#pragma unroll
+      for (int jn = 0; jn < TJ; ++jn) {   // rows = x rows, columns = output features; small terms first
+        const bf16x8 wh = __builtin_bit_cast(bf16x8, wf.hi[jn]), wl = __builtin_bit_cast(bf16x8, wf.lo[jn]);
+        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl, acc[i][jn], 0, 0, 0);
+        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh, acc[i][jn], 0, 0, 0);
+        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc[i][jn], 0, 0, 0);
+      }
+    }
+  };
+
+  WFrag w0, w1, w2, w3;
+  load_step(0);
+  load_w(0, w0);
+  load_w(1, w1);
+  load_w(2, w2);
+  store_step(0);
+  __syncthreads();
+  for (int st = 0; st < nsteps; ++st) {
+    const int buf = st & 1, ch = st * kStepChunks;
+    if (st + 1 < nsteps) load_step(st + 1);
+    load_w(ch + 3, w3);
+    chunk_mfma(buf, 0, w0);
+    load_w(ch + 4, w0);
+    chunk_mfma(buf, 1, w1);
+    load_w(ch + 5, w1);
+    chunk_mfma(buf, 2, w2);
+    load_w(ch + 6, w2);
+    chunk_mfma(buf, 3, w3);
+    if (st + 1 < nsteps) store_step(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: accumulator register v of lane l is (row 8 (v / 4) + 4 (l / 32) + v % 4, column l % 32)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    uint32_t zero_rows = 0;                            // bit v: row of register v is masked
+    if (row_mask) {
+#pragma unroll
+      for (int v4 = 0; v4 < 4; ++v4) {                 // rows 8 v4 + 4 half .. + 3 are consecutive: one 4-byte load
+        const long long m = m0 + wm + i * 32 + 8 * v4 + 4 * half;
+        uint32_t four = 0;
+        if (m + 3 < M && ((m & 3) == 0)) four = *reinterpret_cast<const uint32_t*>(row_mask + m);
+        else
+          for (int e = 0; e < 4; ++e) if (m + e < M && row_mask[m + e]) four |= 0xffu << (8 * e);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if ((four >> (8 * e)) & 0xffu) zero_rows |= 1u << (4 * v4 + e);
+      }
+    }
+#pragma unroll
+    for (int jn = 0; jn < TJ; ++jn) {
+      const int n = n0 + wn + jn * 32 + r32;
+      const float bv = (bias && n < N) ? bias[n] : 0.f;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const long long m = m0 + wm + i * 32 + 8 * (v / 4) + 4 * half + (v % 4);
+        if (m < M && n < N) out[m * N + n] = ((zero_rows >> v) & 1u) ? 0.f : acc[i][jn][v] + bv;
+      }
+    }
+  }
+}
+
+__global__ void pack_weight_kernel(const float* __restrict__ w, int N, int K, int n_pad, uint16_t* __restrict__ packed) {
+  const long long total = (long long)(K / kChunk) * n_pad * kChunk;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int kl = (int)(idx % kChunk);
+    const int n = (int)((idx / kChunk) % n_pad);
+    const int chunk = (int)(idx / kChunk / n_pad);
+    const float v = n < N ? w[(long long)n * K + chunk * kChunk + kl] : 0.f;
+    const uint32_t bits = __float_as_uint(v), hb = bits & 0xffff0000u;
+    const uint32_t lb = __float_as_uint(v - __uint_as_float(hb));
+    const long long o = ((long long)chunk * 2 * n_pad + n) * kChunk + kl;
+    packed[o] = (uint16_t)(hb >> 16);
+    packed[o + (long long)n_pad * kChunk] = (uint16_t)(lb >> 16);
+  }
+}
+
+static inline int n_padded(int n) { return (n + 127) / 128 * 128; }
+
+}  // namespace linear
+
+extern "C" {
+
+int dynmask_set_error(int code, const char* what);   // msda_capi.hip (shared last-error slot)
+
+size_t linear_hip_packed_weight_bytes(int out_features, int in_features) {
+  if (out_features <= 0 || in_features <= 0 || in_features % linear::kStepK != 0) return 0;
+  return (size_t)(in_features / linear::kChunk) * 2 * linear::n_padded(out_features) * linear::kChunk * sizeof(uint16_t);
+}
+
+int linear_hip_pack_weight_f32(const float* weight, int out_features, int in_features, void* packed, void* stream) {
+  if (out_features <= 0 || in_features <= 0) return dynmask_set_error(LINEAR_ERR_BAD_DIMS, "linear: bad dimensions");
+  if (in_features % linear::kStepK != 0)
+    return dynmask_set_error(LINEAR_ERR_UNSUPPORTED, "linear: in_features must be a multiple of 64");
+  if (!weight || !packed) return dynmask_set_error(LINEAR_ERR_NULL_POINTER, "linear: null pointer argument");
+  hipLaunchKernelGGL(linear::pack_weight_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, weight, out_features,
+                     in_features, linear::n_padded(out_features), static_cast<uint16_t*>(packed));
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : dynmask_set_error((int)e, hipGetErrorString(e));
+}
+
+int linear_hip_packed_f32(const float* x, const void* packed, const float* bias, const uint8_t* row_mask,
+                          long long rows, int in_features, int out_features, float* out, void* stream) {
+  if (rows < 0 || in_features <= 0 || out_features <= 0)
+    return dynmask_set_error(LINEAR_ERR_BAD_DIMS, "linear: bad dimensions");
+  if (in_features % linear::kStepK != 0)
+    return dynmask_set_error(LINEAR_ERR_UNSUPPORTED, "linear: in_features must be a multiple of 64");
+  if (rows == 0) return 0;
+  const long long mt = (rows + linear::BM - 1) / linear::BM;
+  if (mt >= (1ll << 31) || (long long)(out_features + 63) / 64 > 65535)
+    return dynmask_set_error(LINEAR_ERR_BAD_DIMS, "linear: problem too large");
+  if (!x || !packed || !out) return dynmask_set_error(LINEAR_ERR_NULL_POINTER, "linear: null pointer argument");
+  const int n_pad = linear::n_padded(out_features);
+  const uint32_t* pk = static_cast<const uint32_t*>(packed);
+  hipStream_t st = (hipStream_t)stream;
+  // 128 columns per workgroup unless that leaves CUs idle
+  if (out_features > 64 && mt * ((out_features + 127) / 128) >= 512) {
+    dim3 grid((unsigned)mt, (unsigned)((out_features + 127) / 128));
+    hipLaunchKernelGGL((linear::linear_packed<2>), grid, dim3(linear::kThreads), 0, st, x, pk, bias, row_mask, rows,
+                       in_features, out_features, n_pad, out);
+  } else {
+    dim3 grid((unsigned)mt, (unsigned)((out_features + 63) / 64));
+    hipLaunchKernelGGL((linear::linear_packed<1>), grid, dim3(linear::kThreads), 0, st, x, pk, bias, row_mask, rows,
+                       in_features, out_features, n_pad, out);
+  }
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : dynmask_set_error((int)e, hipGetErrorString(e));
+}
+
+}  // extern "C"

@@ -355,3 +355,59 @@ def patch_embed_packed_forward(x, packed, embed_dim, patch, bias=None, channels_
     if rc != 0:
         _raise(rc)
     return out
+
+
+def linear_packed_supported(x, weight):
+    """True when include/linear_hip.h covers `F.linear(x, weight)`: fp32 GPU tensors, in_features % 64 == 0."""
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.dim() == 2
+            and x.shape[-1] == weight.shape[1] and weight.shape[1] % 64 == 0)
+
+
+def linear_pack_weight(weight):
+    """Split + re-order an [out_features, in_features] fp32 GPU weight once for linear_packed_forward."""
+    lib = _lib.load()
+    _check("weight", weight, weight.device)
+    if weight.dtype != torch.float32 or weight.dim() != 2:
+        raise RuntimeError("linear_pack_weight: expected a float32 [out_features, in_features] weight")
+    n, k = weight.shape
+    nbytes = lib.linear_hip_packed_weight_bytes(n, k)
+    if nbytes == 0:
+        raise RuntimeError("linear_pack_weight: in_features must be a multiple of 64")
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+    with torch.cuda.device(weight.device):
+        rc = lib.linear_hip_pack_weight_f32(weight.data_ptr(), n, k, packed.data_ptr(),
+                                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc != 0:
+        _raise(rc)
+    return packed
+
+
+def linear_packed_forward(x, packed, out_features, bias=None, row_mask=None):
+    """`F.linear(x, W, bias)` with split-bf16 products (~2e-5 of the output scale) from weights prepared by
+    linear_pack_weight; rows whose `row_mask` entry is True are written as zeros (the masked_fill of
+    ops/modules/ms_deform_attn.py:96-97).  x [..., in_features] contiguous -> [..., out_features]."""
+    lib = _lib.load()
+    _check("x", x, x.device)
+    _check("packed", packed, x.device)
+    if x.dtype != torch.float32 or x.dim() < 1:
+        raise RuntimeError("linear_packed_forward: expected a float32 x [..., in_features]")
+    k, n = x.shape[-1], int(out_features)
+    rows = x.numel() // k if k else 0
+    if bias is not None:
+        _check("bias", bias, x.device)
+        if bias.dtype != torch.float32 or bias.shape != (n,):
+            raise RuntimeError("linear_packed_forward: bias must be float32 [out_features]")
+    if row_mask is not None:
+        _check("row_mask", row_mask, x.device)
+        if row_mask.dtype not in (torch.bool, torch.uint8) or row_mask.numel() != rows:
+            raise RuntimeError("linear_packed_forward: row_mask must be bool / uint8 with one entry per row")
+    if packed.dtype != torch.uint8 or packed.numel() == 0 or packed.numel() != lib.linear_hip_packed_weight_bytes(n, k):
+        raise RuntimeError("linear_packed_forward: `packed` does not belong to a [%d, %d] weight" % (n, k))
+    out = torch.empty(x.shape[:-1] + (n,), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.linear_hip_packed_f32(x.data_ptr(), packed.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                       row_mask.data_ptr() if row_mask is not None else None, rows, k, n, out.data_ptr(),
+                                       ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc != 0:
+        _raise(rc)
+    return out

@@ -2,14 +2,18 @@
 
 Host-side mirror of the reference's ops/modules/ms_deform_attn.py:30-116: same constructor arguments, parameter
 names (`sampling_offsets`, `attention_weights`, `value_proj`, `output_proj` -- reference checkpoints load unchanged),
-initialisation (:54-76), argument meaning and errors of `forward` (:79-116).  The four projections stay
-PyTorch-ROCm GEMMs (rocBLAS / hipBLASLt).  The sampling runs in libmsda_hip.so:
+initialisation (:54-76), argument meaning and errors of `forward` (:79-116).  The sampling runs in libmsda_hip.so:
 
   * when gradients are needed: softmax + sampling locations in PyTorch, then `MSDeformAttnFunction` (autograd),
     exactly the reference's data flow;
   * otherwise (inference): `ms_deform_attn_forward_fused` -- the kernel takes the raw Linear outputs and the
     reference points and does softmax, location arithmetic and sampling in one pass.
     Set `MSDeformAttn.fuse_prologue = False` (or env UNINEXT_AMD_NO_FUSED=1) to force the two-step path.
+
+The four projections are PyTorch-ROCm GEMMs (hipBLASLt) whenever autograd records; at inference they run
+include/linear_hip.h -- split-bf16 products on the matrix cores from weights packed once per module (~2e-5 of the
+output scale per layer), with the padding-mask fill folded into value_proj's epilogue.
+`MSDeformAttn.fast_linear = False` (or env UNINEXT_AMD_EXACT_LINEAR=1) keeps the fp32 library GEMMs.
 """
 import math
 import os
@@ -32,6 +36,7 @@ def _is_power_of_2(n):
 
 class MSDeformAttn(nn.Module):
     fuse_prologue = os.environ.get("UNINEXT_AMD_NO_FUSED", "0") != "1"
+    fast_linear = os.environ.get("UNINEXT_AMD_EXACT_LINEAR", "0") != "1"
 
     def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4):
         super().__init__()
@@ -66,6 +71,25 @@ class MSDeformAttn(nn.Module):
         constant_(self.value_proj.bias.data, 0.0)
         xavier_uniform_(self.output_proj.weight.data)
         constant_(self.output_proj.bias.data, 0.0)
+
+    # -- projections ------------------------------------------------------------------------------------------
+    def _project(self, lin, x, row_mask=None):
+        """`lin(x)` (then zero the rows where row_mask is True).  Inference on the GPU: include/linear_hip.h from a
+        packed copy of the weight cached on the Linear and rebuilt when the parameter changes."""
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or lin.weight.requires_grad)
+        if self.fast_linear and not needs_grad and x.is_contiguous() and MSDA.linear_packed_supported(x, lin.weight):
+            w = lin.weight
+            key = (w.data_ptr(), w._version, str(w.device))
+            cache = lin.__dict__.get("_msda_packed")
+            if cache is None or cache[0] != key:
+                cache = (key, MSDA.linear_pack_weight(w.detach().contiguous()))
+                lin.__dict__["_msda_packed"] = cache
+            mask = row_mask.contiguous() if row_mask is not None else None
+            return MSDA.linear_packed_forward(x, cache[1], w.shape[0], lin.bias, mask)
+        y = lin(x)
+        if row_mask is not None:
+            y = y.masked_fill(row_mask[..., None], float(0))
+        return y
 
     # -- the two ways to run the sampling ---------------------------------------------------------------------
     def _sample_autograd(self, value, shapes, level_start, reference_points, offsets, logits):
@@ -102,12 +126,10 @@ class MSDeformAttn(nn.Module):
             raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(
                 reference_points.shape[-1]))
 
-        value = self.value_proj(input_flatten)
-        if input_padding_mask is not None:
-            value = value.masked_fill(input_padding_mask[..., None], float(0))
+        value = self._project(self.value_proj, input_flatten, input_padding_mask)
         value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
-        offsets = self.sampling_offsets(query)        # (N, Lq, M*L*P*2)
-        logits = self.attention_weights(query)        # (N, Lq, M*L*P)
+        offsets = self._project(self.sampling_offsets, query)        # (N, Lq, M*L*P*2)
+        logits = self._project(self.attention_weights, query)        # (N, Lq, M*L*P)
 
         if self._can_fuse(value, reference_points, offsets, logits):
             sampled = MSDA.ms_deform_attn_forward_fused(value, input_spatial_shapes, input_level_start_index,
@@ -115,4 +137,4 @@ class MSDeformAttn(nn.Module):
         else:
             sampled = self._sample_autograd(value, input_spatial_shapes, input_level_start_index, reference_points,
                                             offsets, logits)
-        return self.output_proj(sampled)
+        return self._project(self.output_proj, sampled)
