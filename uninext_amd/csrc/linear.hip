@@ -20,7 +20,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4v __attribute__((__vector_size__(16)));
 using msda::f32x4;
 
-constexpr int kThreads = 256, BM = 128;
+constexpr int kThreads = 256;
 constexpr int kChunk = 16, kStepChunks = 4, kStepK = kChunk * kStepChunks;   // 64 k per barrier
 
 __device__ __forceinline__ void split8(const float (&v)[8], u32x4v& hi, u32x4v& lo) {
@@ -35,43 +35,52 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4v& hi, u32x4v& 
   }
 }
 
-template <int TJ>
+template <int TJ, int BM>
 __global__ void __launch_bounds__(kThreads, 2)
 linear_packed(const float* __restrict__ x, const uint32_t* __restrict__ packed, const float* __restrict__ bias,
               const uint8_t* __restrict__ row_mask, long long M, int K, int N, int n_pad, float* __restrict__ out) {
-  __shared__ __attribute__((aligned(16))) uint32_t As[2][2][kStepChunks][BM][8];   // [buffer][hi / lo][chunk][row][16 bf16]
+  // [buffer][hi / lo][chunk][row (+1 pad row per chunk: staggers the banks of the staging stores)][16 bf16]
+  __shared__ __attribute__((aligned(16))) uint32_t As[2][2][kStepChunks][BM + 1][8];
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const long long m0 = (long long)blockIdx.x * BM;
   const int n0 = blockIdx.y * (64 * TJ);
 
-  // staging: this thread owns (row tid % 128, k half tid / 128) of every chunk of a step: 8 consecutive floats
-  const int s_row = tid & 127, s_half = tid >> 7;
-  long long mr = m0 + s_row;
-  mr = mr < M ? mr : M - 1;
-  const float* a_ptr = x + mr * K + s_half * 8;
-  f32x4 a_reg[kStepChunks][2];
+  // staging: a step is 128 rows x 64 k = 16 pieces of 16 bytes per row; lane t % 16 takes piece t % 16 of rows
+  // t / 16 + 16 r, so a wave instruction reads 4 rows x 256 contiguous bytes (full lines)
+  const int s_piece = tid & 15, s_row0 = tid >> 4;
+  constexpr int kRows = BM / 16, TI = BM / 64;   // rows staged per thread; 32-row MFMA tiles per wave
+  const float* a_ptr[kRows];
+#pragma unroll
+  for (int r = 0; r < kRows; ++r) {
+    long long mr = m0 + s_row0 + 16 * r;
+    mr = mr < M ? mr : M - 1;
+    a_ptr[r] = x + mr * K + s_piece * 4;
+  }
+  f32x4 a_reg[kRows];
   auto load_step = [&](int st) {
 #pragma unroll
-    for (int cc = 0; cc < kStepChunks; ++cc) {
-      const float* p = a_ptr + st * kStepK + cc * kChunk;
-      a_reg[cc][0] = *reinterpret_cast<const f32x4*>(p);
-      a_reg[cc][1] = *reinterpret_cast<const f32x4*>(p + 4);
-    }
+    for (int r = 0; r < kRows; ++r) a_reg[r] = *reinterpret_cast<const f32x4*>(a_ptr[r] + st * kStepK);
   };
   auto store_step = [&](int buf) {
+    const int cc = s_piece >> 2, w2 = (s_piece & 3) * 2;   // chunk of the step, word pair inside the row's 16 bf16
 #pragma unroll
-    for (int cc = 0; cc < kStepChunks; ++cc) {
-      const float v[8] = {a_reg[cc][0][0], a_reg[cc][0][1], a_reg[cc][0][2], a_reg[cc][0][3],
-                          a_reg[cc][1][0], a_reg[cc][1][1], a_reg[cc][1][2], a_reg[cc][1][3]};
-      u32x4v hi, lo;
-      split8(v, hi, lo);
-      *reinterpret_cast<u32x4v*>(&As[buf][0][cc][s_row][s_half * 4]) = hi;
-      *reinterpret_cast<u32x4v*>(&As[buf][1][cc][s_row][s_half * 4]) = lo;
+    for (int r = 0; r < kRows; ++r) {
+      uint32_t hi[2], lo[2];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const float fa = a_reg[r][2 * p], fb = a_reg[r][2 * p + 1];
+        const uint32_t ah = __float_as_uint(fa) & 0xffff0000u, bh = __float_as_uint(fb) & 0xffff0000u;
+        const uint32_t al = __float_as_uint(fa - __uint_as_float(ah)), bl = __float_as_uint(fb - __uint_as_float(bh));
+        hi[p] = (ah >> 16) | bh;
+        lo[p] = (al >> 16) | (bl & 0xffff0000u);
+      }
+      *reinterpret_cast<uint2*>(&As[buf][0][cc][s_row0 + 16 * r][w2]) = make_uint2(hi[0], hi[1]);
+      *reinterpret_cast<uint2*>(&As[buf][1][cc][s_row0 + 16 * r][w2]) = make_uint2(lo[0], lo[1]);
     }
   };
 
-  const int wm = (wv >> 1) * 64, wn = (wv & 1) * 32 * TJ;
+  const int wm = (wv >> 1) * (BM / 2), wn = (wv & 1) * 32 * TJ;
   const int r32 = lane & 31, half = lane >> 5;
   const uint32_t* w_lane = packed + (long long)(n0 + wn + r32) * 8 + half * 4;
   const long long chunk_stride = (long long)2 * n_pad * 8, part_stride = (long long)n_pad * 8;
@@ -87,9 +96,9 @@ linear_packed(const float* __restrict__ x, const uint32_t* __restrict__ packed, 
     }
   };
 
-  f32x16 acc[2][TJ];
+  f32x16 acc[TI][TJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
     for (int jn = 0; jn < TJ; ++jn)
 #pragma unroll
@@ -97,7 +106,7 @@ linear_packed(const float* __restrict__ x, const uint32_t* __restrict__ packed, 
 
   auto chunk_mfma = [&](int buf, int cc, const WFrag& wf) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TI; ++i) {
       const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(&As[buf][0][cc][wm + i * 32 + r32][half * 4]));
       const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(&As[buf][1][cc][wm + i * 32 + r32][half * 4]));
 #pragma unroll
@@ -134,7 +143,7 @@ linear_packed(const float* __restrict__ x, const uint32_t* __restrict__ packed, 
 
   // epilogue: accumulator register v of lane l is (row 8 (v / 4) + 4 (l / 32) + v % 4, column l % 32)
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < TI; ++i) {
     uint32_t zero_rows = 0;                            // bit v: row of register v is masked
     if (row_mask) {
 #pragma unroll
@@ -207,7 +216,10 @@ int linear_hip_packed_f32(const float* x, const void* packed, const float* bias,
   if (in_features % linear::kStepK != 0)
     return dynmask_set_error(LINEAR_ERR_UNSUPPORTED, "linear: in_features must be a multiple of 64");
   if (rows == 0) return 0;
-  const long long mt = (rows + linear::BM - 1) / linear::BM;
+  // 64-row tiles: a tile is only K / 64 steps long (4 at K = 256), so the kernel lives on the number of workgroups
+  // a CU can overlap -- 33 KB of LDS each instead of 66 KB
+  constexpr int BM = 64;
+  const long long mt = (rows + BM - 1) / BM;
   if (mt >= (1ll << 31) || (long long)(out_features + 63) / 64 > 65535)
     return dynmask_set_error(LINEAR_ERR_BAD_DIMS, "linear: problem too large");
   if (!x || !packed || !out) return dynmask_set_error(LINEAR_ERR_NULL_POINTER, "linear: null pointer argument");
@@ -217,11 +229,11 @@ int linear_hip_packed_f32(const float* x, const void* packed, const float* bias,
   // 128 columns per workgroup unless that leaves CUs idle
   if (out_features > 64 && mt * ((out_features + 127) / 128) >= 512) {
     dim3 grid((unsigned)mt, (unsigned)((out_features + 127) / 128));
-    hipLaunchKernelGGL((linear::linear_packed<2>), grid, dim3(linear::kThreads), 0, st, x, pk, bias, row_mask, rows,
+    hipLaunchKernelGGL((linear::linear_packed<2, BM>), grid, dim3(linear::kThreads), 0, st, x, pk, bias, row_mask, rows,
                        in_features, out_features, n_pad, out);
   } else {
     dim3 grid((unsigned)mt, (unsigned)((out_features + 63) / 64));
-    hipLaunchKernelGGL((linear::linear_packed<1>), grid, dim3(linear::kThreads), 0, st, x, pk, bias, row_mask, rows,
+    hipLaunchKernelGGL((linear::linear_packed<1, BM>), grid, dim3(linear::kThreads), 0, st, x, pk, bias, row_mask, rows,
                        in_features, out_features, n_pad, out);
   }
   const hipError_t e = hipGetLastError();
