@@ -198,53 +198,71 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4v& hi, u32x4v& 
   }
 }
 
-template <int KS, bool NHWC, int TJ>
+template <int KS, bool NHWC, int TJ, int BM>
 __global__ void __launch_bounds__(kThreads, 2)
 patch_embed_packed(const float* __restrict__ x, const uint32_t* __restrict__ packed, const float* __restrict__ bias, Geom g,
                    int e_pad, float* __restrict__ out) {
-  constexpr int BM = 128;
-  constexpr int VW = KS >= 4 ? 4 : 2;
-  __shared__ __attribute__((aligned(16))) uint32_t As[2][2][kStepChunks][BM][8];   // [buffer][hi / lo][chunk][patch][16 bf16]
+  constexpr int VW = KS >= 4 ? 4 : 2;                 // floats per load (a kx run)
+  constexpr int PP = kChunk / VW;                     // pieces per (patch, chunk)
+  constexpr int kItems = kStepChunks * BM * PP / kThreads;   // staging items per thread and step
+  constexpr int TI = BM / 64;
+  // [buffer][hi / lo][chunk][patch (+1 pad row: staggers the banks of the staging stores)][16 bf16]
+  __shared__ __attribute__((aligned(16))) uint32_t As[2][2][kStepChunks][BM + 1][8];
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * (64 * TJ);
   const int HpWp = g.Hp * g.Wp;
 
-  // staging items: (chunk of the step, patch row, half = 8 consecutive k); this thread owns item tid of every chunk
-  const int s_row = tid & 127, s_half = tid >> 7;
-  int64_t a_base;
-  {
-    int m = m0 + s_row;
+  // staging item i = tid + 256 r: piece i % PP (VW consecutive k), patch (i / PP) % BM, chunk i / (PP BM) -- the
+  // lanes of a wave run along the pieces of a patch and then along patches, i.e. along contiguous image memory
+  int64_t a_base[kItems];
+#pragma unroll
+  for (int r = 0; r < kItems; ++r) {
+    const int i = tid + r * kThreads;
+    int m = m0 + (i / PP) % BM;
     m = m < g.Mtot ? m : g.Mtot - 1;
     const int b = m / HpWp, sp = m - b * HpWp;
     const int py = sp / g.Wp, px = sp - py * g.Wp;
-    a_base = ((int64_t)b * g.C * g.H + (int64_t)py * KS) * g.W + (int64_t)px * KS;
+    a_base[r] = ((int64_t)b * g.C * g.H + (int64_t)py * KS) * g.W + (int64_t)px * KS;
   }
-  float a_reg[kStepChunks][8];
+  float a_reg[kItems][VW];
   auto load_step = [&](int st) {
 #pragma unroll
-    for (int cc = 0; cc < kStepChunks; ++cc)
+    for (int r = 0; r < kItems; ++r) {
+      const int i = tid + r * kThreads;
+      const int kk = st * kStepK + (i / (PP * BM)) * kChunk + (i % PP) * VW;   // (c * KS + ky) * KS + kx
+      const int c = kk / (KS * KS), rr = kk % (KS * KS);
+      const int ky = rr / KS, kx = rr % KS;
+      const float* p = x + a_base[r] + ((int64_t)c * g.H + ky) * g.W + kx;
 #pragma unroll
-      for (int j = 0; j < 8 / VW; ++j) {
-        const int kk = st * kStepK + cc * kChunk + s_half * 8 + j * VW;   // (c * KS + ky) * KS + kx, kx multiple of VW
-        const int c = kk / (KS * KS), r = kk % (KS * KS);
-        const int ky = r / KS, kx = r % KS;
-        const float* p = x + a_base + ((int64_t)c * g.H + ky) * g.W + kx;
-#pragma unroll
-        for (int e = 0; e < VW; ++e) a_reg[cc][j * VW + e] = p[e];
-      }
+      for (int e = 0; e < VW; ++e) a_reg[r][e] = p[e];
+    }
   };
   auto store_step = [&](int buf) {
 #pragma unroll
-    for (int cc = 0; cc < kStepChunks; ++cc) {
-      u32x4v hi, lo;
-      split8(a_reg[cc], hi, lo);
-      *reinterpret_cast<u32x4v*>(&As[buf][0][cc][s_row][s_half * 4]) = hi;
-      *reinterpret_cast<u32x4v*>(&As[buf][1][cc][s_row][s_half * 4]) = lo;
+    for (int r = 0; r < kItems; ++r) {
+      const int i = tid + r * kThreads;
+      const int piece = i % PP, row = (i / PP) % BM, cc = i / (PP * BM);
+      uint32_t hi[VW / 2], lo[VW / 2];
+#pragma unroll
+      for (int p = 0; p < VW / 2; ++p) {
+        const float fa = a_reg[r][2 * p], fb = a_reg[r][2 * p + 1];
+        const uint32_t ah = __float_as_uint(fa) & 0xffff0000u, bh = __float_as_uint(fb) & 0xffff0000u;
+        const uint32_t al = __float_as_uint(fa - __uint_as_float(ah)), bl = __float_as_uint(fb - __uint_as_float(bh));
+        hi[p] = (ah >> 16) | bh;
+        lo[p] = (al >> 16) | (bl & 0xffff0000u);
+      }
+      if constexpr (VW == 4) {
+        *reinterpret_cast<uint2*>(&As[buf][0][cc][row][piece * 2]) = make_uint2(hi[0], hi[1]);
+        *reinterpret_cast<uint2*>(&As[buf][1][cc][row][piece * 2]) = make_uint2(lo[0], lo[1]);
+      } else {
+        As[buf][0][cc][row][piece] = hi[0];
+        As[buf][1][cc][row][piece] = lo[0];
+      }
     }
   };
 
-  const int wm = (wv >> 1) * 64, wn = (wv & 1) * 32 * TJ;
+  const int wm = (wv >> 1) * (BM / 2), wn = (wv & 1) * 32 * TJ;
   const int r32 = lane & 31, half = lane >> 5;
   const int nb = n0 + wn + r32;
   const uint32_t* w_lane = packed + (int64_t)nb * 8 + half * 4;
@@ -261,9 +279,9 @@ patch_embed_packed(const float* __restrict__ x, const uint32_t* __restrict__ pac
     }
   };
 
-  f32x16 acc[2][TJ];
+  f32x16 acc[TI][TJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
     for (int jn = 0; jn < TJ; ++jn)
 #pragma unroll
@@ -271,7 +289,7 @@ patch_embed_packed(const float* __restrict__ x, const uint32_t* __restrict__ pac
 
   auto chunk_mfma = [&](int buf, int cc, const WFrag& wf) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TI; ++i) {
       const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(&As[buf][0][cc][wm + i * 32 + r32][half * 4]));
       const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(&As[buf][1][cc][wm + i * 32 + r32][half * 4]));
 #pragma unroll
@@ -310,7 +328,7 @@ patch_embed_packed(const float* __restrict__ x, const uint32_t* __restrict__ pac
   }
 
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
     for (int jn = 0; jn < TJ; ++jn) {
       if constexpr (NHWC) {
@@ -352,22 +370,30 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int E, int K, in
 
 static inline int e_padded(int E) { return (E + 127) / 128 * 128; }
 
-template <int KS>
-static int launch_packed(const float* x, const uint32_t* packed, const float* bias, const Geom& g, int channels_last,
-                         float* out, hipStream_t stream) {
+template <int KS, int BM>
+static int launch_packed_bm(const float* x, const uint32_t* packed, const float* bias, const Geom& g, int channels_last,
+                            float* out, hipStream_t stream) {
   const int e_pad = e_padded(g.E);
-  const long long mt = (g.Mtot + 127) / 128;
+  const long long mt = (g.Mtot + BM - 1) / BM;
   const bool wide = g.E > 64 && mt * ((g.E + 127) / 128) >= 512;   // 128 channels per workgroup unless CUs would idle
   if (wide) {
     dim3 grid((unsigned)mt, (unsigned)((g.E + 127) / 128));
-    if (channels_last) hipLaunchKernelGGL((patch_embed_packed<KS, true, 2>), grid, dim3(kThreads), 0, stream, x, packed, bias, g, e_pad, out);
-    else hipLaunchKernelGGL((patch_embed_packed<KS, false, 2>), grid, dim3(kThreads), 0, stream, x, packed, bias, g, e_pad, out);
+    if (channels_last) hipLaunchKernelGGL((patch_embed_packed<KS, true, 2, BM>), grid, dim3(kThreads), 0, stream, x, packed, bias, g, e_pad, out);
+    else hipLaunchKernelGGL((patch_embed_packed<KS, false, 2, BM>), grid, dim3(kThreads), 0, stream, x, packed, bias, g, e_pad, out);
   } else {
     dim3 grid((unsigned)mt, (unsigned)((g.E + 63) / 64));
-    if (channels_last) hipLaunchKernelGGL((patch_embed_packed<KS, true, 1>), grid, dim3(kThreads), 0, stream, x, packed, bias, g, e_pad, out);
-    else hipLaunchKernelGGL((patch_embed_packed<KS, false, 1>), grid, dim3(kThreads), 0, stream, x, packed, bias, g, e_pad, out);
+    if (channels_last) hipLaunchKernelGGL((patch_embed_packed<KS, true, 1, BM>), grid, dim3(kThreads), 0, stream, x, packed, bias, g, e_pad, out);
+    else hipLaunchKernelGGL((patch_embed_packed<KS, false, 1, BM>), grid, dim3(kThreads), 0, stream, x, packed, bias, g, e_pad, out);
   }
   return (int)hipGetLastError();
+}
+
+template <int KS>
+static int launch_packed(const float* x, const uint32_t* packed, const float* bias, const Geom& g, int channels_last,
+                         float* out, hipStream_t stream) {
+  static const int forced = std::getenv("PATCH_EMBED_BM") ? std::atoi(std::getenv("PATCH_EMBED_BM")) : 0;
+  if (forced == 128) return launch_packed_bm<KS, 128>(x, packed, bias, g, channels_last, out, stream);
+  return launch_packed_bm<KS, 64>(x, packed, bias, g, channels_last, out, stream);
 }
 
 template <int KS, int BM, int BN>
