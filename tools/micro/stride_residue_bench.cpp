@@ -26,10 +26,11 @@ __global__ void __launch_bounds__(256) gather(const char* __restrict__ buf, int 
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       p = p * 1664525u + 1013904223u;
-      int pix = local ? (base_pix + (int)((p >> 8) % 4096u)) % npix : (int)((p >> 8) % (unsigned)npix);
+      int pix = (local & 1) ? (base_pix + (int)((p >> 8) % 4096u)) % npix : (int)((p >> 8) % (unsigned)npix);
       const size_t off = mode == 3 ? ((size_t)res * npix + pix) * 128     // head-major layout: dense slice per residue
                                    : (size_t)pix * 1024 + res * 128;
-      v[u] = *reinterpret_cast<const f32x4*>(buf + off + lane8 * 16);
+      const f32x4* ptr = reinterpret_cast<const f32x4*>(buf + off + lane8 * 16);
+      v[u] = (local & 2) ? __builtin_nontemporal_load(ptr) : *ptr;   // bit 1 of `local`: non-temporal (L1-bypassing) loads
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) acc += v[u];
@@ -61,8 +62,9 @@ int main(int argc, char** argv) {
     return ms / 5 * 1e3;
   };
   const double lines = (double)blocks * 32 * iters * 8;
-  for (int local = 0; local < 2; ++local) {
-    printf("%s pixels, base shift %d B: %0.f lines of 128 B per launch\n", local ? "band-local" : "random", shift, lines);
+  for (int local = 0; local < 4; ++local) {
+    printf("%s pixels%s, base shift %d B: %0.f lines of 128 B per launch\n", (local & 1) ? "band-local" : "random",
+           (local & 2) ? ", NON-TEMPORAL loads" : "", shift, lines);
     for (int r = 0; r < 8; ++r) {
       const float us = run(0, r, local);
       printf("  all workgroups residue %d: %8.1f us  %6.2f TB/s\n", r, us, lines * 128 / us * 1e-6);
