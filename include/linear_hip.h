@@ -38,6 +38,15 @@ int linear_hip_pack_weight_f32(const float* weight, int out_features, int in_fea
 int linear_hip_packed_f32(const float* x, const void* packed, const float* bias, const uint8_t* row_mask,
                           long long rows, int in_features, int out_features, float* out, void* stream);
 
+/*
+ * The same with the output written HEAD-MAJOR for msda_hip_forward_fused_hm_f32 (include/msda_hip.h): x is
+ * [images * rows_per_image, in_features], out is [images, out_features / 32, rows_per_image, 32] -- the value
+ * projection of MSDeformAttn with its `view(N, S, heads, 32)` transposed to (N, heads, S, 32) at no extra cost.
+ */
+int linear_hip_packed_hm_f32(const float* x, const void* packed, const float* bias, const uint8_t* row_mask,
+                             long long rows, int in_features, int out_features, int rows_per_image, float* out,
+                             void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -106,6 +106,18 @@ int msda_hip_forward_fused_f32(const float* value, const int64_t* spatial_shapes
                                int num_point, float* output, void* stream);
 
 /*
+ * The same with `value` in HEAD-MAJOR layout [batch, num_heads, spatial_size, channels] -- what
+ * linear_hip_packed_hm_f32 (include/linear_hip.h) writes for the value projection.  A head's pixels are then 128 bytes
+ * apart instead of num_heads * 128, which the gather likes better (6-15 % at the R50 shapes).  Encoder-sized calls
+ * only (num_levels == num_point == 4, num_query >= 1024); otherwise MSDA_ERR_UNSUPPORTED.
+ */
+int msda_hip_forward_fused_hm_f32(const float* value_head_major, const int64_t* spatial_shapes,
+                                  const int64_t* level_start_index, const float* reference_points, int ref_dim,
+                                  const float* sampling_offsets, const float* attn_logits, int batch, int spatial_size,
+                                  int num_heads, int channels, int num_levels, int num_query, int num_point,
+                                  float* output, void* stream);
+
+/*
  * Kernel selection (tuning / A-B measurement only; results are identical up to fp32
  * summation order).  which: 0 = forward, 1 = backward.  variant: 0 = automatic (default),
  * 1 = generic one-thread-per-output kernel, 2 = lane-group gather kernel, higher numbers as

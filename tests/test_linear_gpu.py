@@ -79,9 +79,11 @@ def test_layer_with_fast_projections(ref_dim, dev):
     mask = torch.zeros(N, S, dtype=torch.bool, device=dev)
     mask[1, -40:] = True
     sh, lsi = level_tensors(levels, dev)
+    from uninext_amd import _lib
     with torch.no_grad():
         fast = layer(query, ref, src, sh, lsi, mask)
         assert "_msda_packed" in layer.value_proj.__dict__
+        assert _lib.last_kernel("forward") == ("msda_fwd_lg3_fused" if Lq >= 1024 else "msda_fwd_fused")
         MSDeformAttn.fast_linear = False
         try:
             exact = layer(query, ref, src, sh, lsi, mask)
@@ -101,6 +103,59 @@ def test_layer_with_fast_projections(ref_dim, dev):
     q2 = query.clone().requires_grad_(True)                     # autograd recording: library GEMMs, has a backward
     layer(q2, ref, src, sh, lsi, mask).sum().backward()
     assert q2.grad is not None
+
+
+@pytest.mark.parametrize("ref_dim", [2, 4])
+def test_fused_lg3_and_head_major_vs_oracle(ref_dim, dev):
+    """Encoder-sized fused forward (msda_fwd_lg3 with the prologue folded in) on both value layouts against the C
+    oracle fed with the PyTorch prologue, and the head-major Linear epilogue against a transpose."""
+    import torch.nn.functional as F
+    from oracle import msda_oracle
+    from uninext_amd import _lib, ext
+    from uninext_amd.workloads import level_tensors
+    torch.manual_seed(31)
+    levels = ((40, 50), (20, 25), (10, 13), (5, 7))
+    S = sum(h * w for h, w in levels)
+    N, M, L, P, Lq = 2, 8, 4, 4, 1500
+    sh, lsi = level_tensors(levels, dev)
+    value = torch.randn(N, S, M, 32, device=dev)
+    ref = torch.rand(N, Lq, L, ref_dim, device=dev)
+    if ref_dim == 4:
+        ref[..., 2:] = ref[..., 2:] * 0.3 + 0.05
+    offsets = torch.randn(N, Lq, M * L * P * 2, device=dev) * 3
+    logits = torch.randn(N, Lq, M * L * P, device=dev)
+    offsets[1, 5, 7] = float("nan")
+    out = ext.ms_deform_attn_forward_fused(value, sh, lsi, ref, offsets, logits, P)
+    assert _lib.last_kernel("forward") == "msda_fwd_lg3_fused"
+    value_hm = value.permute(0, 2, 1, 3).contiguous()
+    out_hm = ext.ms_deform_attn_forward_fused(value_hm, sh, lsi, ref, offsets, logits, P, value_head_major=True)
+    assert _lib.last_kernel("forward") == "msda_fwd_lg3_fused"
+    assert torch.equal(torch.nan_to_num(out), torch.nan_to_num(out_hm))            # same arithmetic, other addresses
+    off = offsets.view(N, Lq, M, L, P, 2)
+    w = F.softmax(logits.view(N, Lq, M, L * P), -1).view(N, Lq, M, L, P)
+    if ref_dim == 2:
+        wh = torch.stack([sh[..., 1], sh[..., 0]], -1)
+        loc = ref[:, :, None, :, None, :] + off / wh[None, None, None, :, None, :]
+    else:
+        loc = ref[:, :, None, :, None, :2] + off / P * ref[:, :, None, :, None, 2:] * 0.5
+    idx = torch.cat([torch.arange(0, 300), torch.arange(Lq - 300, Lq)]).to(dev)
+    want = msda_oracle.forward(value, sh, lsi, loc[:, idx].contiguous(), w[:, idx].contiguous())
+    got = out[:, idx].cpu().numpy()
+    ok = np.isfinite(want)                                   # the NaN offset poisons one (query, head) in the oracle
+    assert np.abs(got[ok] - want[ok]).max() < 1e-4
+    assert torch.isfinite(out).all()                         # the kernel drops the out-of-range sample instead
+    with pytest.raises(RuntimeError, match="head-major"):    # decoder-sized call: no head-major kernel
+        ext.ms_deform_attn_forward_fused(value_hm, sh, lsi, ref[:, :100].contiguous(), offsets[:, :100].contiguous(),
+                                         logits[:, :100].contiguous(), P, value_head_major=True)
+    # head-major Linear epilogue == transpose of the row-major result
+    lin = torch.nn.Linear(256, 256).to(dev)
+    x = torch.randn(N, S, 256, device=dev)
+    mask = torch.rand(N, S, device=dev) < 0.1
+    with torch.no_grad():
+        packed = ext.linear_pack_weight(lin.weight)
+        rm = ext.linear_packed_forward(x, packed, 256, lin.bias, mask)
+        hm = ext.linear_packed_forward(x, packed, 256, lin.bias, mask, head_major_rows=S)
+    assert hm.shape == (N, 8, S, 32) and torch.equal(hm, rm.view(N, S, 8, 32).permute(0, 2, 1, 3))
 
 
 def test_errors(dev):

@@ -33,6 +33,7 @@ def timeit(fn, reps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--rotate", type=int, default=1, help="cycle through this many distinct (query, src) sets (cold caches)")
     args = ap.parse_args()
     dev = "cuda"
     torch.manual_seed(0)
@@ -43,14 +44,21 @@ def main():
     with torch.no_grad():
         layer.sampling_offsets.weight.normal_(0, 0.01)
         layer.attention_weights.weight.normal_(0, 0.1)
-    src = torch.randn(N, S, 256, device=dev)
-    query = src + torch.randn(N, S, 256, device=dev) * 0.1
+    srcs = [torch.randn(N, S, 256, device=dev) for _ in range(args.rotate)]
+    queries = [t + torch.randn(N, S, 256, device=dev) * 0.1 for t in srcs]
+    src, query = srcs[0], queries[0]
+    turn = [0]
+
+    def whole_layer():
+        k = turn[0] % args.rotate
+        turn[0] += 1
+        return layer(queries[k], ref, srcs[k], sh, lsi, None)
     ref = workloads.encoder_reference_points(levels, dev)[None, :, None, :].expand(N, S, 4, 2).contiguous()
     sh, lsi = workloads.level_tensors(levels, dev)
     with torch.no_grad():
         for fuse in (True, False):
             MSDeformAttn.fuse_prologue = fuse
-            whole = timeit(lambda: layer(query, ref, src, sh, lsi, None), args.reps)
+            whole = timeit(whole_layer, args.reps)
             value = layer.value_proj(src).view(N, S, 8, 32)
             off, lg = layer.sampling_offsets(query), layer.attention_weights(query)
             if fuse:

@@ -11,14 +11,15 @@ ABI_VERSION = 1
 EXPORTS = (
     "msda_hip_abi_version", "msda_hip_last_error",
     "msda_hip_forward_f32", "msda_hip_forward_f64", "msda_hip_backward_f32", "msda_hip_backward_f64",
-    "msda_hip_forward_fused_f32",
+    "msda_hip_forward_fused_f32", "msda_hip_forward_fused_hm_f32",
     "msda_hip_set_variant", "msda_hip_get_variant", "msda_hip_variant_name", "msda_hip_last_kernel",
 )
 
 DYNMASK_EXPORTS = ("dynmask_hip_forward_f32", "aligned_bilinear_hip_f32")   # include/dynmask_hip.h
 PATCH_EMBED_EXPORTS = ("patch_embed_hip_f32", "patch_embed_hip_packed_weight_bytes", "patch_embed_hip_pack_weight_f32",
                        "patch_embed_hip_packed_f32")                           # include/patch_embed_hip.h
-LINEAR_EXPORTS = ("linear_hip_packed_weight_bytes", "linear_hip_pack_weight_f32", "linear_hip_packed_f32")  # include/linear_hip.h
+LINEAR_EXPORTS = ("linear_hip_packed_weight_bytes", "linear_hip_pack_weight_f32", "linear_hip_packed_f32",
+                  "linear_hip_packed_hm_f32")                                   # include/linear_hip.h
 CONV3X3_EXPORTS = ("conv3x3_hip_f32", "conv3x3_hip_packed_weight_bytes", "conv3x3_hip_pack_weight_f32",
                    "conv3x3_hip_packed_f32")                                   # include/conv3x3_hip.h
 
@@ -46,6 +47,10 @@ def load():
         g.argtypes, g.restype = [p, p, p, p, p, p, i, i, i, i, i, i, i, p, p, p, p], i
     lib.msda_hip_forward_fused_f32.argtypes = [p, p, p, p, i, p, p, i, i, i, i, i, i, i, p, p]
     lib.msda_hip_forward_fused_f32.restype = i
+    lib.msda_hip_forward_fused_hm_f32.argtypes = lib.msda_hip_forward_fused_f32.argtypes
+    lib.msda_hip_forward_fused_hm_f32.restype = i
+    lib.linear_hip_packed_hm_f32.argtypes = [p, p, p, p, ctypes.c_longlong, i, i, i, p, p]
+    lib.linear_hip_packed_hm_f32.restype = i
     lib.dynmask_hip_forward_f32.argtypes = [p, p, p, p, i, i, i, i, i, i, p, p]
     lib.dynmask_hip_forward_f32.restype = i
     lib.aligned_bilinear_hip_f32.argtypes, lib.aligned_bilinear_hip_f32.restype = [p, i, i, i, i, p, p], i

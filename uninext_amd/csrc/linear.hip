@@ -38,7 +38,8 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4v& hi, u32x4v& 
 template <int TJ, int BM>
 __global__ void __launch_bounds__(kThreads, 2)
 linear_packed(const float* __restrict__ x, const uint32_t* __restrict__ packed, const float* __restrict__ bias,
-              const uint8_t* __restrict__ row_mask, long long M, int K, int N, int n_pad, float* __restrict__ out) {
+              const uint8_t* __restrict__ row_mask, long long M, int K, int N, int n_pad, int hm_rows,
+              float* __restrict__ out) {
   // [buffer][hi / lo][chunk][row (+1 pad row per chunk: staggers the banks of the staging stores)][16 bf16]
   __shared__ __attribute__((aligned(16))) uint32_t As[2][2][kStepChunks][BM + 1][8];
 
@@ -164,7 +165,15 @@ linear_packed(const float* __restrict__ x, const uint32_t* __restrict__ packed, 
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
         const long long m = m0 + wm + i * 32 + 8 * (v / 4) + 4 * half + (v % 4);
-        if (m < M && n < N) out[m * N + n] = ((zero_rows >> v) & 1u) ? 0.f : acc[i][jn][v] + bv;
+        if (m < M && n < N) {
+          const float r = ((zero_rows >> v) & 1u) ? 0.f : acc[i][jn][v] + bv;
+          if (hm_rows == 0) {
+            out[m * N + n] = r;
+          } else {   // head-major [image, head = n / 32, row in image, n % 32]: a lane row still writes 128 contiguous bytes
+            const long long img = m / hm_rows, sr = m - img * hm_rows;
+            out[((img * (N / 32) + (n >> 5)) * hm_rows + sr) * 32 + (n & 31)] = r;
+          }
+        }
       }
     }
   }
@@ -209,8 +218,8 @@ int linear_hip_pack_weight_f32(const float* weight, int out_features, int in_fea
   return e == hipSuccess ? 0 : dynmask_set_error((int)e, hipGetErrorString(e));
 }
 
-int linear_hip_packed_f32(const float* x, const void* packed, const float* bias, const uint8_t* row_mask,
-                          long long rows, int in_features, int out_features, float* out, void* stream) {
+static int linear_impl(const float* x, const void* packed, const float* bias, const uint8_t* row_mask, long long rows,
+                       int in_features, int out_features, int hm_rows, float* out, void* stream) {
   if (rows < 0 || in_features <= 0 || out_features <= 0)
     return dynmask_set_error(LINEAR_ERR_BAD_DIMS, "linear: bad dimensions");
   if (in_features % linear::kStepK != 0)
@@ -230,14 +239,28 @@ int linear_hip_packed_f32(const float* x, const void* packed, const float* bias,
   if (out_features > 64 && mt * ((out_features + 127) / 128) >= 512) {
     dim3 grid((unsigned)mt, (unsigned)((out_features + 127) / 128));
     hipLaunchKernelGGL((linear::linear_packed<2, BM>), grid, dim3(linear::kThreads), 0, st, x, pk, bias, row_mask, rows,
-                       in_features, out_features, n_pad, out);
+                       in_features, out_features, n_pad, hm_rows, out);
   } else {
     dim3 grid((unsigned)mt, (unsigned)((out_features + 63) / 64));
     hipLaunchKernelGGL((linear::linear_packed<1, BM>), grid, dim3(linear::kThreads), 0, st, x, pk, bias, row_mask, rows,
-                       in_features, out_features, n_pad, out);
+                       in_features, out_features, n_pad, hm_rows, out);
   }
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : dynmask_set_error((int)e, hipGetErrorString(e));
+}
+
+
+int linear_hip_packed_f32(const float* x, const void* packed, const float* bias, const uint8_t* row_mask,
+                          long long rows, int in_features, int out_features, float* out, void* stream) {
+  return linear_impl(x, packed, bias, row_mask, rows, in_features, out_features, 0, out, stream);
+}
+
+int linear_hip_packed_hm_f32(const float* x, const void* packed, const float* bias, const uint8_t* row_mask,
+                             long long rows, int in_features, int out_features, int rows_per_image, float* out,
+                             void* stream) {
+  if (rows_per_image <= 0 || out_features % 32 != 0 || (rows >= 0 && rows % rows_per_image != 0))
+    return dynmask_set_error(LINEAR_ERR_BAD_DIMS, "linear (head-major): out_features must be a multiple of 32 and rows a multiple of rows_per_image");
+  return linear_impl(x, packed, bias, row_mask, rows, in_features, out_features, rows_per_image, out, stream);
 }
 
 }  // extern "C"

@@ -127,21 +127,42 @@ int msda_hip_backward_f64(const double* grad_output, const double* value, const 
                                grad_value, grad_sampling_loc, grad_attn_weight, stream);
 }
 
+static int forward_fused_impl(const float* value, int head_major, const int64_t* spatial_shapes,
+                              const int64_t* level_start_index, const float* reference_points, int ref_dim,
+                              const float* sampling_offsets, const float* attn_logits, const msda::Dims& d, float* output,
+                              void* stream) {
+  if (int rc = check_dims(d)) return rc;
+  if (!msda::fused_forward_ok(d, ref_dim))
+    return fail(MSDA_ERR_UNSUPPORTED, "fused forward needs channels == 32, num_levels * num_point == 16, ref_dim 2 or 4");
+  if (head_major && !msda::fused_forward_hm_ok(d, ref_dim))
+    return fail(MSDA_ERR_UNSUPPORTED, "fused forward on head-major value needs num_levels == num_point == 4 and num_query >= 1024");
+  if (d.N == 0 || d.Lq == 0) return 0;
+  if (!value || !spatial_shapes || !level_start_index || !reference_points || !sampling_offsets || !attn_logits || !output)
+    return fail(MSDA_ERR_NULL_POINTER, "null pointer argument");
+  const char* name = "";
+  const int rc = msda::launch_forward_fused(value, head_major, spatial_shapes, level_start_index, reference_points,
+                                            ref_dim, sampling_offsets, attn_logits, d, output, (hipStream_t)stream, &name);
+  g_last_kernel[0].store(name, std::memory_order_relaxed);
+  return finish(rc, "msda_hip_forward_fused");
+}
+
 int msda_hip_forward_fused_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
                                const float* reference_points, int ref_dim, const float* sampling_offsets,
                                const float* attn_logits, int batch, int spatial_size, int num_heads, int channels,
                                int num_levels, int num_query, int num_point, float* output, void* stream) {
   const msda::Dims d{batch, spatial_size, num_heads, channels, num_levels, num_query, num_point};
-  if (int rc = check_dims(d)) return rc;
-  if (!msda::fused_forward_ok(d, ref_dim))
-    return fail(MSDA_ERR_UNSUPPORTED, "fused forward needs channels == 32, num_levels * num_point == 16, ref_dim 2 or 4");
-  if (d.N == 0 || d.Lq == 0) return 0;
-  if (!value || !spatial_shapes || !level_start_index || !reference_points || !sampling_offsets || !attn_logits || !output)
-    return fail(MSDA_ERR_NULL_POINTER, "null pointer argument");
-  const int rc = msda::launch_forward_fused(value, spatial_shapes, level_start_index, reference_points, ref_dim,
-                                            sampling_offsets, attn_logits, d, output, (hipStream_t)stream);
-  g_last_kernel[0].store("msda_fwd_fused", std::memory_order_relaxed);
-  return finish(rc, "msda_hip_forward_fused");
+  return forward_fused_impl(value, 0, spatial_shapes, level_start_index, reference_points, ref_dim, sampling_offsets,
+                            attn_logits, d, output, stream);
+}
+
+int msda_hip_forward_fused_hm_f32(const float* value_head_major, const int64_t* spatial_shapes,
+                                  const int64_t* level_start_index, const float* reference_points, int ref_dim,
+                                  const float* sampling_offsets, const float* attn_logits, int batch, int spatial_size,
+                                  int num_heads, int channels, int num_levels, int num_query, int num_point,
+                                  float* output, void* stream) {
+  const msda::Dims d{batch, spatial_size, num_heads, channels, num_levels, num_query, num_point};
+  return forward_fused_impl(value_head_major, 1, spatial_shapes, level_start_index, reference_points, ref_dim,
+                            sampling_offsets, attn_logits, d, output, stream);
 }
 
 int msda_hip_set_variant(int which, int variant) {

@@ -86,9 +86,10 @@ enum Variant { kAuto = 0, kGeneric = 1, kLaneGroup = 2, kTiled = 3, kTiledL0 = 4
 
 // msda_fwd.hip: forward with the MSDeformAttn prologue (softmax + sampling locations) fused in.
 bool fused_forward_ok(const Dims& d, int ref_dim);
-int launch_forward_fused(const float* value, const int64_t* shapes, const int64_t* lsi, const float* ref_points,
-                         int ref_dim, const float* offsets, const float* logits, const Dims& d, float* out,
-                         hipStream_t stream);
+bool fused_forward_hm_ok(const Dims& d, int ref_dim);   // head-major value: encoder-sized calls only
+int launch_forward_fused(const float* value, int head_major, const int64_t* shapes, const int64_t* lsi,
+                         const float* ref_points, int ref_dim, const float* offsets, const float* logits, const Dims& d,
+                         float* out, hipStream_t stream, const char** kernel_name);
 
 // msda_bwd_tiled.hip: backward with grad_value privatised in LDS (fp32, D = 32, P = 4, Lq == S).
 bool tiled_backward_ok(const Dims& d);

@@ -19,6 +19,8 @@
 //                            `value` (2.8 MB / image at the R50 shapes, inside its 4 MiB L2).
 #include <type_traits>
 
+#include <cstdlib>
+
 #include "msda_common.hpp"
 
 namespace msda {
@@ -300,9 +302,25 @@ bool fused_forward_ok(const Dims& d, int ref_dim) {
          (int64_t)d.S * d.M * 128 < (int64_t)kOobOffset && d.N <= 65535;
 }
 
-int launch_forward_fused(const float* value, const int64_t* shapes, const int64_t* lsi, const float* ref_points,
-                         int ref_dim, const float* offsets, const float* logits, const Dims& d, float* out,
-                         hipStream_t stream) {
+static inline bool lg3_ok(const Dims& d);
+template <int REFD>
+static int launch_lg3_t(const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc,
+                        const float* attn, const float* ref_points, const Dims& d, int head_major, float* out,
+                        hipStream_t stream);
+
+bool fused_forward_hm_ok(const Dims& d, int ref_dim) { return fused_forward_ok(d, ref_dim) && lg3_ok(d); }
+
+int launch_forward_fused(const float* value, int head_major, const int64_t* shapes, const int64_t* lsi,
+                         const float* ref_points, int ref_dim, const float* offsets, const float* logits, const Dims& d,
+                         float* out, hipStream_t stream, const char** kernel_name) {
+  static const bool use_lg3 = !(std::getenv("MSDA_HIP_FUSED_LG3") && std::getenv("MSDA_HIP_FUSED_LG3")[0] == '0');
+  if (lg3_ok(d) && (use_lg3 || head_major)) {   // encoder-sized calls: the lg3 structure with the prologue folded in
+    *kernel_name = "msda_fwd_lg3_fused";
+    return ref_dim == 2 ? launch_lg3_t<2>(value, shapes, lsi, offsets, logits, ref_points, d, head_major, out, stream)
+                        : launch_lg3_t<4>(value, shapes, lsi, offsets, logits, ref_points, d, head_major, out, stream);
+  }
+  if (head_major) return -5;   // MSDA_ERR_UNSUPPORTED: the small-call fused kernel reads the reference layout only
+  *kernel_name = "msda_fwd_fused";
   constexpr int kPairs = kBlock / 8;
   const size_t lds = kLevelTableBytes + (size_t)kPairs * (16 * 32 + 16);
   dim3 grid((unsigned)(d.M * ((d.Lq + kPairs - 1) / kPairs)), (unsigned)d.N);
@@ -474,10 +492,18 @@ constexpr int kL3Threads = 1024;
 constexpr int kL3RecPair = 8 * 32 + 16;
 constexpr int kL3LdsBytes = kLevelTableBytes + (kClSlots + 1) * 128 + (kL3Threads / 8) * kL3RecPair;
 
+// REFD 0: `loc` / `attn` are normalised sampling locations and softmaxed weights (the operator).  REFD 2 / 4: they are
+// the RAW Linear outputs (offsets, logits) and `ref_points` [N, Lq, L, REFD] the reference points: softmax over the
+// pair's 16 logits and the location arithmetic of ops/modules/ms_deform_attn.py:99-112 run in the kernel
+// (msda_fwd_fused's prologue on this kernel's sample assignment: lane j holds samples j and 8 + j).
+// head_major != 0: `value` is [N, M, S, 32] (written that way by the value projection, include/linear_hip.h) -- a
+// head's pixels are then 128 bytes apart instead of 1 KB.
+template <int REFD>
 __global__ void __launch_bounds__(kL3Threads, 8)
 msda_fwd_lg3(const float* __restrict__ value, const int64_t* __restrict__ shapes,
              const int64_t* __restrict__ lsi, const float* __restrict__ loc,
-             const float* __restrict__ attn, Dims d, float* __restrict__ out) {
+             const float* __restrict__ attn, const float* __restrict__ ref_points, Dims d, int head_major,
+             float* __restrict__ out) {
   constexpr int G = 8, LPT = 16, P = 4, kPairs = kL3Threads / G;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* smp_H = reinterpret_cast<int*>(smem);
@@ -502,10 +528,10 @@ msda_fwd_lg3(const float* __restrict__ value, const int64_t* __restrict__ shapes
 
   const int b = blockIdx.y;
   const int m = blockIdx.x % d.M;
-  const uint32_t pix_bytes = (uint32_t)d.M * 128u;
+  const uint32_t pix_bytes = head_major ? 128u : (uint32_t)d.M * 128u;
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(value) + (int64_t)b * d.S * d.M * 32, 0, (int)((uint32_t)d.S * pix_bytes), 0x00020000);
-  const uint32_t head_off = (uint32_t)m * 128u;
+      const_cast<float*>(value) + (int64_t)b * d.S * d.M * 32, 0, (int)((uint32_t)d.S * (uint32_t)d.M * 128u), 0x00020000);
+  const uint32_t head_off = head_major ? (uint32_t)m * (uint32_t)d.S * 128u : (uint32_t)m * 128u;
   for (int i = tid >> 3; i <= nres && fits; i += kL3Threads / 8) {   // slot `nres` stays zero: dead corners read it
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (i < nres) v = buffer_load_f32x4(rsrc, (uint32_t)(res_pix0 + i) * pix_bytes + (uint32_t)(tid & 7) * 16u, head_off);
@@ -529,6 +555,32 @@ msda_fwd_lg3(const float* __restrict__ value, const int64_t* __restrict__ shapes
     lc1 = *reinterpret_cast<const float2*>(loc + pair * (2 * LPT) + 2 * (8 + j));
     at0 = attn[pair * LPT + j];
     at1 = attn[pair * LPT + 8 + j];
+  }
+  if constexpr (REFD != 0) {   // raw offsets / logits -> locations / softmax weights; dead pairs carry zeros through
+    auto gmax = [](float v) {
+      v = fmaxf(v, fdpp<0xB1>(v)); v = fmaxf(v, fdpp<0x4E>(v)); v = fmaxf(v, fdpp<0x141>(v));
+      return v;
+    };
+    const float mx = gmax(fmaxf(at0, at1));
+    const float e0 = __expf(at0 - mx), e1 = __expf(at1 - mx);
+    const float inv = 1.0f / group8_add(e0 + e1);
+    at0 = e0 * inv;
+    at1 = e1 * inv;
+    const float* rp = ref_points + ((int64_t)b * d.Lq + (live ? q : 0)) * LPT / P * REFD;
+    const int l0 = j / P, l1 = 2 + j / P;               // levels of samples j and 8 + j (L = P = 4)
+    if constexpr (REFD == 2) {
+      const float2 r0 = *reinterpret_cast<const float2*>(rp + l0 * 2), r1 = *reinterpret_cast<const float2*>(rp + l1 * 2);
+      lc0.x = r0.x + lc0.x / (float)smp_W[j];
+      lc0.y = r0.y + lc0.y / (float)smp_H[j];
+      lc1.x = r1.x + lc1.x / (float)smp_W[8 + j];
+      lc1.y = r1.y + lc1.y / (float)smp_H[8 + j];
+    } else {
+      const float4 r0 = *reinterpret_cast<const float4*>(rp + l0 * 4), r1 = *reinterpret_cast<const float4*>(rp + l1 * 4);
+      lc0.x = r0.x + lc0.x / (float)P * r0.z * 0.5f;
+      lc0.y = r0.y + lc0.y / (float)P * r0.w * 0.5f;
+      lc1.x = r1.x + lc1.x / (float)P * r1.z * 0.5f;
+      lc1.y = r1.y + lc1.y / (float)P * r1.w * 0.5f;
+    }
   }
   auto prepare = [&](int s, int slot, float lx, float ly, float a, bool resident) {
     const int H = smp_H[s], W = smp_W[s];
@@ -613,19 +665,27 @@ static inline bool lg3_ok(const Dims& d) {
          d.Lq >= 1024;   // a 128-query workgroup copies 35 KB: pointless for a handful of queries
 }
 
-static int launch_lg3(const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc,
-                      const float* attn, const Dims& d, float* out, hipStream_t stream) {
+template <int REFD>
+static int launch_lg3_t(const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc,
+                        const float* attn, const float* ref_points, const Dims& d, int head_major, float* out,
+                        hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_fwd_lg3),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_fwd_lg3<REFD>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kL3LdsBytes);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   constexpr int kPairs = kL3Threads / 8;
   dim3 grid((unsigned)(d.M * ((d.Lq + kPairs - 1) / kPairs)), (unsigned)d.N);
-  hipLaunchKernelGGL(msda_fwd_lg3, grid, dim3(kL3Threads), kL3LdsBytes, stream, value, shapes, lsi, loc, attn, d, out);
+  hipLaunchKernelGGL(msda_fwd_lg3<REFD>, grid, dim3(kL3Threads), kL3LdsBytes, stream, value, shapes, lsi, loc, attn,
+                     ref_points, d, head_major, out);
   return (int)hipGetLastError();
+}
+
+static int launch_lg3(const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc,
+                      const float* attn, const Dims& d, float* out, hipStream_t stream) {
+  return launch_lg3_t<0>(value, shapes, lsi, loc, attn, nullptr, d, 0, out, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -104,15 +104,24 @@ def fused_forward_supported(value, reference_points, num_levels, num_points):
             and num_levels * num_points == 16 and num_points % 2 == 0 and reference_points.shape[-1] in (2, 4))
 
 
+def fused_forward_hm_supported(value_shape, num_levels, num_points, num_query):
+    """Geometry msda_hip_forward_fused_hm_f32 covers: 32 channels per head, 4 levels x 4 points, encoder-sized calls."""
+    return value_shape[-1] == 32 and num_levels == 4 and num_points == 4 and num_query >= 1024
+
+
 def ms_deform_attn_forward_fused(value, spatial_shapes, level_start_index, reference_points, sampling_offsets,
-                                 attention_logits, num_points):
+                                 attention_logits, num_points, value_head_major=False):
     """MSDeformAttn.forward's softmax + sampling-location arithmetic + sampling in ONE kernel
     (ops/modules/ms_deform_attn.py:99-113).  `sampling_offsets` [N, Lq, M*L*P*2] and `attention_logits`
     [N, Lq, M*L*P] are the raw Linear outputs, `reference_points` [N, Lq, L, 2|4].  Inference only (no autograd).
+    value_head_major: `value` is [N, M, S, D] (linear_packed_forward(..., head_major_rows=S)) instead of [N, S, M, D].
     Raises RuntimeError for unsupported geometry -- check fused_forward_supported() first."""
     lib, _ = _prep(value, spatial_shapes, level_start_index, sampling_offsets, attention_logits,
                    extra=(("reference_points", reference_points),))
-    N, S, M, D = value.shape
+    if value_head_major:
+        N, M, S, D = value.shape
+    else:
+        N, S, M, D = value.shape
     L = spatial_shapes.shape[0]
     Lq = sampling_offsets.shape[1]
     P = int(num_points)
@@ -122,7 +131,8 @@ def ms_deform_attn_forward_fused(value, spatial_shapes, level_start_index, refer
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
     with torch.cuda.device(value.device):
         stream = torch.cuda.current_stream().cuda_stream
-        rc = lib.msda_hip_forward_fused_f32(
+        fn = lib.msda_hip_forward_fused_hm_f32 if value_head_major else lib.msda_hip_forward_fused_f32
+        rc = fn(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), reference_points.data_ptr(),
             int(reference_points.shape[-1]), sampling_offsets.data_ptr(), attention_logits.data_ptr(),
             N, S, M, D, L, Lq, P, out.data_ptr(), ctypes.c_void_p(stream))
@@ -382,10 +392,12 @@ def linear_pack_weight(weight):
     return packed
 
 
-def linear_packed_forward(x, packed, out_features, bias=None, row_mask=None):
+def linear_packed_forward(x, packed, out_features, bias=None, row_mask=None, head_major_rows=0):
     """`F.linear(x, W, bias)` with split-bf16 products (~2e-5 of the output scale) from weights prepared by
     linear_pack_weight; rows whose `row_mask` entry is True are written as zeros (the masked_fill of
-    ops/modules/ms_deform_attn.py:96-97).  x [..., in_features] contiguous -> [..., out_features]."""
+    ops/modules/ms_deform_attn.py:96-97).  x [..., in_features] contiguous -> [..., out_features].
+    head_major_rows = S > 0: x is [N, S, in_features] and the result is [N, out_features // 32, S, 32] (head-major
+    `value` for ms_deform_attn_forward_fused(..., value_head_major=True))."""
     lib = _lib.load()
     _check("x", x, x.device)
     _check("packed", packed, x.device)
@@ -403,11 +415,21 @@ def linear_packed_forward(x, packed, out_features, bias=None, row_mask=None):
             raise RuntimeError("linear_packed_forward: row_mask must be bool / uint8 with one entry per row")
     if packed.dtype != torch.uint8 or packed.numel() == 0 or packed.numel() != lib.linear_hip_packed_weight_bytes(n, k):
         raise RuntimeError("linear_packed_forward: `packed` does not belong to a [%d, %d] weight" % (n, k))
-    out = torch.empty(x.shape[:-1] + (n,), dtype=torch.float32, device=x.device)
+    hm = int(head_major_rows)
+    if hm:
+        if x.dim() != 3 or x.shape[1] != hm or n % 32:
+            raise RuntimeError("linear_packed_forward: head-major output needs x [N, S, in_features] and out_features % 32 == 0")
+        out = torch.empty((x.shape[0], n // 32, hm, 32), dtype=torch.float32, device=x.device)
+    else:
+        out = torch.empty(x.shape[:-1] + (n,), dtype=torch.float32, device=x.device)
+    b_ptr = bias.data_ptr() if bias is not None else None
+    m_ptr = row_mask.data_ptr() if row_mask is not None else None
     with torch.cuda.device(x.device):
-        rc = lib.linear_hip_packed_f32(x.data_ptr(), packed.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                       row_mask.data_ptr() if row_mask is not None else None, rows, k, n, out.data_ptr(),
-                                       ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if hm:
+            rc = lib.linear_hip_packed_hm_f32(x.data_ptr(), packed.data_ptr(), b_ptr, m_ptr, rows, k, n, hm, out.data_ptr(), st)
+        else:
+            rc = lib.linear_hip_packed_f32(x.data_ptr(), packed.data_ptr(), b_ptr, m_ptr, rows, k, n, out.data_ptr(), st)
     if rc != 0:
         _raise(rc)
     return out
