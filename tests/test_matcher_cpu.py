@@ -55,6 +55,39 @@ def test_ota_indices_bit_exact(name):
             assert len(set(q.tolist())) == len(q)                            # a query serves one gt
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_batched_dynamic_k_equals_reference_loop(seed):
+    """The sync-free top-10 + rank-mask selection picks exactly what the reference's per-gt topk loop picks, also with
+    many, clustered and duplicated ground-truth boxes (repair loop exercised)."""
+    g = torch.Generator().manual_seed(100 + seed)
+    bs, Q, T = 2, 300, 16
+    logits = torch.randn(bs, Q, T, generator=g) * 2
+    centers = torch.rand(bs, Q, 2, generator=g)
+    boxes = torch.cat([centers, 0.03 + 0.3 * torch.rand(bs, Q, 2, generator=g) ** 2], -1)
+    targets = []
+    for b in range(bs):
+        G = int(torch.randint(1, 40, (1,), generator=g))
+        c = 0.3 + 0.4 * torch.rand(G, 2, generator=g) if seed % 2 else torch.rand(G, 2, generator=g)
+        tb = torch.cat([c, 0.05 + 0.25 * torch.rand(G, 2, generator=g)], -1)
+        if G > 3:
+            tb[1] = tb[0]                                   # duplicated gt: contested queries
+        pm = torch.zeros(G, T, dtype=torch.bool)
+        pm[torch.arange(G), torch.randint(0, T, (G,), generator=g)] = True
+        targets.append({"boxes": tb, "positive_map": pm, "labels": torch.zeros(G, dtype=torch.int64),
+                        "image_size": torch.tensor([800.0, 1333.0, 800.0, 1333.0])})
+    outputs = {"pred_logits": logits, "pred_boxes": boxes}
+    m = HungarianMatcherVL(cost_class=2, cost_bbox=5, cost_giou=2)
+    fast = m.forward_ota(outputs, targets)
+    HungarianMatcherVL.batched_topk = False
+    try:
+        ref = m.forward_ota(outputs, targets)
+    finally:
+        HungarianMatcherVL.batched_topk = True
+    for b in range(bs):
+        assert torch.equal(fast[0][b][0], ref[0][b][0]) and torch.equal(fast[0][b][1], ref[0][b][1])
+        assert torch.equal(torch.as_tensor(fast[1][b]), torch.as_tensor(ref[1][b]))
+
+
 def test_box_helpers_against_closed_forms():
     a = torch.tensor([[0.0, 0.0, 2.0, 2.0], [1.0, 1.0, 3.0, 3.0]])
     b = torch.tensor([[1.0, 1.0, 2.0, 2.0], [4.0, 4.0, 5.0, 5.0]])

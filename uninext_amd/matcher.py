@@ -87,6 +87,8 @@ class HungarianMatcherVL(nn.Module):
     targets: list (bs) of {"boxes": [G, 4] cxcywh, "positive_map": [G, T] bool (or index) token map}
     """
 
+    batched_topk = True   # dynamic-k selection without a host sync per ground-truth box (same indices; see the tests)
+
     def __init__(self, cost_class: float = 1, cost_bbox: float = 1, cost_giou: float = 1, cost_mask: float = 1):
         super().__init__()
         self.cost_class, self.cost_bbox, self.cost_giou, self.cost_mask = cost_class, cost_bbox, cost_giou, cost_mask
@@ -172,9 +174,18 @@ class HungarianMatcherVL(nn.Module):
         n_query = len(pair_wise_ious)
         topk_ious, _ = torch.topk(pair_wise_ious, min(n_query, OTA_TOPK_CANDIDATES), dim=0)
         dynamic_ks = torch.clamp(topk_ious.sum(0).int(), min=1)
-        for g in range(num_gt):
-            _, pos = torch.topk(cost[:, g], k=dynamic_ks[g].item(), largest=False)
-            matching[:, g][pos] = 1.0
+        if self.batched_topk:
+            # the reference loops over the gts with one `.item()` (host sync) each (matcher.py:399-402); k_g <= 10, so one
+            # top-10 over all columns and a rank mask select the same entries without leaving the device
+            kmax = min(n_query, OTA_TOPK_CANDIDATES)
+            _, pos = torch.topk(cost, k=kmax, dim=0, largest=False)                      # [kmax, G], ascending cost
+            keep = torch.arange(kmax, device=cost.device)[:, None] < dynamic_ks[None, :]
+            cols = torch.arange(num_gt, device=cost.device)[None, :].expand_as(pos)
+            matching[pos[keep], cols[keep]] = 1.0
+        else:
+            for g in range(num_gt):
+                _, pos = torch.topk(cost[:, g], k=dynamic_ks[g].item(), largest=False)
+                matching[:, g][pos] = 1.0
 
         claims = matching.sum(1)            # NOTE: the reference never refreshes this inside the repair loop below
         if (claims > 1).sum() > 0:
