@@ -47,6 +47,15 @@ int linear_hip_packed_hm_f32(const float* x, const void* packed, const float* bi
                              long long rows, int in_features, int out_features, int rows_per_image, float* out,
                              void* stream);
 
+/*
+ * Extended form for the layers around the attention (DeformableTransformerEncoderLayer.forward,
+ * deformable_transformer_dino.py:354-370): the input is x + x_add when x_add != NULL (`with_pos_embed(src, pos)`, :363,
+ * folded into the operand load) and `activation` 1 applies ReLU in the epilogue (`activation(linear1(src))`, :355).
+ */
+int linear_hip_packed_ex_f32(const float* x, const float* x_add, const void* packed, const float* bias,
+                             const uint8_t* row_mask, long long rows, int in_features, int out_features, int activation,
+                             float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

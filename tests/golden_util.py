@@ -13,7 +13,7 @@ def _names():
 
 def golden_names():
     """MSDeformAttn operator fixtures (tests/golden/make_golden.py)."""
-    return [n for n in _names() if not n.startswith(("matcher_", "dynmask_", "patch_", "maskhead_"))]
+    return [n for n in _names() if not n.startswith(("matcher_", "dynmask_", "patch_", "maskhead_", "enclayer_"))]
 
 
 def dynmask_names():
@@ -29,6 +29,11 @@ def patch_names():
 def maskhead_names():
     """Static mask head fixtures (tests/golden/make_maskhead_golden.py)."""
     return [n for n in _names() if n.startswith("maskhead_")]
+
+
+def enclayer_names():
+    """Encoder-layer fixtures (tests/golden/make_encoder_layer_golden.py)."""
+    return [n for n in _names() if n.startswith("enclayer_")]
 
 
 def matcher_names():

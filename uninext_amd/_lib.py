@@ -19,7 +19,8 @@ DYNMASK_EXPORTS = ("dynmask_hip_forward_f32", "aligned_bilinear_hip_f32")   # in
 PATCH_EMBED_EXPORTS = ("patch_embed_hip_f32", "patch_embed_hip_packed_weight_bytes", "patch_embed_hip_pack_weight_f32",
                        "patch_embed_hip_packed_f32")                           # include/patch_embed_hip.h
 LINEAR_EXPORTS = ("linear_hip_packed_weight_bytes", "linear_hip_pack_weight_f32", "linear_hip_packed_f32",
-                  "linear_hip_packed_hm_f32")                                   # include/linear_hip.h
+                  "linear_hip_packed_hm_f32", "linear_hip_packed_ex_f32")       # include/linear_hip.h
+LAYERNORM_EXPORTS = ("add_layernorm_hip_f32",)                                 # include/layernorm_hip.h
 CONV3X3_EXPORTS = ("conv3x3_hip_f32", "conv3x3_hip_packed_weight_bytes", "conv3x3_hip_pack_weight_f32",
                    "conv3x3_hip_packed_f32")                                   # include/conv3x3_hip.h
 
@@ -51,6 +52,10 @@ def load():
     lib.msda_hip_forward_fused_hm_f32.restype = i
     lib.linear_hip_packed_hm_f32.argtypes = [p, p, p, p, ctypes.c_longlong, i, i, i, p, p]
     lib.linear_hip_packed_hm_f32.restype = i
+    lib.linear_hip_packed_ex_f32.argtypes = [p, p, p, p, p, ctypes.c_longlong, i, i, i, p, p]
+    lib.linear_hip_packed_ex_f32.restype = i
+    lib.add_layernorm_hip_f32.argtypes = [p, p, p, p, ctypes.c_float, ctypes.c_longlong, i, p, p]
+    lib.add_layernorm_hip_f32.restype = i
     lib.dynmask_hip_forward_f32.argtypes = [p, p, p, p, i, i, i, i, i, i, p, p]
     lib.dynmask_hip_forward_f32.restype = i
     lib.aligned_bilinear_hip_f32.argtypes, lib.aligned_bilinear_hip_f32.restype = [p, i, i, i, i, p, p], i

@@ -37,9 +37,9 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4v& hi, u32x4v& 
 
 template <int TJ, int BM>
 __global__ void __launch_bounds__(kThreads, 2)
-linear_packed(const float* __restrict__ x, const uint32_t* __restrict__ packed, const float* __restrict__ bias,
-              const uint8_t* __restrict__ row_mask, long long M, int K, int N, int n_pad, int hm_rows,
-              float* __restrict__ out) {
+linear_packed(const float* __restrict__ x, const float* __restrict__ x2, const uint32_t* __restrict__ packed,
+              const float* __restrict__ bias, const uint8_t* __restrict__ row_mask, long long M, int K, int N, int n_pad,
+              int hm_rows, int act, float* __restrict__ out) {
   // [buffer][hi / lo][chunk][row (+1 pad row per chunk: staggers the banks of the staging stores)][16 bf16]
   __shared__ __attribute__((aligned(16))) uint32_t As[2][2][kStepChunks][BM + 1][8];
 
@@ -61,7 +61,10 @@ linear_packed(const float* __restrict__ x, const uint32_t* __restrict__ packed, 
   f32x4 a_reg[kRows];
   auto load_step = [&](int st) {
 #pragma unroll
-    for (int r = 0; r < kRows; ++r) a_reg[r] = *reinterpret_cast<const f32x4*>(a_ptr[r] + st * kStepK);
+    for (int r = 0; r < kRows; ++r) {
+      a_reg[r] = *reinterpret_cast<const f32x4*>(a_ptr[r] + st * kStepK);
+      if (x2) a_reg[r] += *reinterpret_cast<const f32x4*>(a_ptr[r] + (x2 - x) + st * kStepK);   // input = x + x2
+    }
   };
   auto store_step = [&](int buf) {
     const int cc = s_piece >> 2, w2 = (s_piece & 3) * 2;   // chunk of the step, word pair inside the row's 16 bf16
@@ -166,7 +169,8 @@ linear_packed(const float* __restrict__ x, const uint32_t* __restrict__ packed, 
       for (int v = 0; v < 16; ++v) {
         const long long m = m0 + wm + i * 32 + 8 * (v / 4) + 4 * half + (v % 4);
         if (m < M && n < N) {
-          const float r = ((zero_rows >> v) & 1u) ? 0.f : acc[i][jn][v] + bv;
+          float r = ((zero_rows >> v) & 1u) ? 0.f : acc[i][jn][v] + bv;
+          if (act == 1) r = fmaxf(r, 0.f);
           if (hm_rows == 0) {
             out[m * N + n] = r;
           } else {   // head-major [image, head = n / 32, row in image, n % 32]: a lane row still writes 128 contiguous bytes
@@ -218,8 +222,9 @@ int linear_hip_pack_weight_f32(const float* weight, int out_features, int in_fea
   return e == hipSuccess ? 0 : dynmask_set_error((int)e, hipGetErrorString(e));
 }
 
-static int linear_impl(const float* x, const void* packed, const float* bias, const uint8_t* row_mask, long long rows,
-                       int in_features, int out_features, int hm_rows, float* out, void* stream) {
+static int linear_impl(const float* x, const float* x2, const void* packed, const float* bias, const uint8_t* row_mask,
+                       long long rows, int in_features, int out_features, int hm_rows, int act, float* out, void* stream) {
+  if (act != 0 && act != 1) return dynmask_set_error(LINEAR_ERR_BAD_DIMS, "linear: activation must be 0 (none) or 1 (relu)");
   if (rows < 0 || in_features <= 0 || out_features <= 0)
     return dynmask_set_error(LINEAR_ERR_BAD_DIMS, "linear: bad dimensions");
   if (in_features % linear::kStepK != 0)
@@ -238,12 +243,12 @@ static int linear_impl(const float* x, const void* packed, const float* bias, co
   // 128 columns per workgroup unless that leaves CUs idle
   if (out_features > 64 && mt * ((out_features + 127) / 128) >= 512) {
     dim3 grid((unsigned)mt, (unsigned)((out_features + 127) / 128));
-    hipLaunchKernelGGL((linear::linear_packed<2, BM>), grid, dim3(linear::kThreads), 0, st, x, pk, bias, row_mask, rows,
-                       in_features, out_features, n_pad, hm_rows, out);
+    hipLaunchKernelGGL((linear::linear_packed<2, BM>), grid, dim3(linear::kThreads), 0, st, x, x2, pk, bias, row_mask, rows,
+                       in_features, out_features, n_pad, hm_rows, act, out);
   } else {
     dim3 grid((unsigned)mt, (unsigned)((out_features + 63) / 64));
-    hipLaunchKernelGGL((linear::linear_packed<1, BM>), grid, dim3(linear::kThreads), 0, st, x, pk, bias, row_mask, rows,
-                       in_features, out_features, n_pad, hm_rows, out);
+    hipLaunchKernelGGL((linear::linear_packed<1, BM>), grid, dim3(linear::kThreads), 0, st, x, x2, pk, bias, row_mask, rows,
+                       in_features, out_features, n_pad, hm_rows, act, out);
   }
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : dynmask_set_error((int)e, hipGetErrorString(e));
@@ -252,7 +257,7 @@ static int linear_impl(const float* x, const void* packed, const float* bias, co
 
 int linear_hip_packed_f32(const float* x, const void* packed, const float* bias, const uint8_t* row_mask,
                           long long rows, int in_features, int out_features, float* out, void* stream) {
-  return linear_impl(x, packed, bias, row_mask, rows, in_features, out_features, 0, out, stream);
+  return linear_impl(x, nullptr, packed, bias, row_mask, rows, in_features, out_features, 0, 0, out, stream);
 }
 
 int linear_hip_packed_hm_f32(const float* x, const void* packed, const float* bias, const uint8_t* row_mask,
@@ -260,7 +265,13 @@ int linear_hip_packed_hm_f32(const float* x, const void* packed, const float* bi
                              void* stream) {
   if (rows_per_image <= 0 || out_features % 32 != 0 || (rows >= 0 && rows % rows_per_image != 0))
     return dynmask_set_error(LINEAR_ERR_BAD_DIMS, "linear (head-major): out_features must be a multiple of 32 and rows a multiple of rows_per_image");
-  return linear_impl(x, packed, bias, row_mask, rows, in_features, out_features, rows_per_image, out, stream);
+  return linear_impl(x, nullptr, packed, bias, row_mask, rows, in_features, out_features, rows_per_image, 0, out, stream);
+}
+
+int linear_hip_packed_ex_f32(const float* x, const float* x_add, const void* packed, const float* bias,
+                             const uint8_t* row_mask, long long rows, int in_features, int out_features, int activation,
+                             float* out, void* stream) {
+  return linear_impl(x, x_add, packed, bias, row_mask, rows, in_features, out_features, 0, activation, out, stream);
 }
 
 }  // extern "C"

@@ -392,12 +392,14 @@ def linear_pack_weight(weight):
     return packed
 
 
-def linear_packed_forward(x, packed, out_features, bias=None, row_mask=None, head_major_rows=0):
+def linear_packed_forward(x, packed, out_features, bias=None, row_mask=None, head_major_rows=0, x_add=None, relu=False):
     """`F.linear(x, W, bias)` with split-bf16 products (~2e-5 of the output scale) from weights prepared by
     linear_pack_weight; rows whose `row_mask` entry is True are written as zeros (the masked_fill of
     ops/modules/ms_deform_attn.py:96-97).  x [..., in_features] contiguous -> [..., out_features].
     head_major_rows = S > 0: x is [N, S, in_features] and the result is [N, out_features // 32, S, 32] (head-major
-    `value` for ms_deform_attn_forward_fused(..., value_head_major=True))."""
+    `value` for ms_deform_attn_forward_fused(..., value_head_major=True)).
+    x_add (same shape as x): the layer's input is x + x_add, added while the operand is loaded (`with_pos_embed`);
+    relu: ReLU in the epilogue.  Neither combines with head_major_rows."""
     lib = _lib.load()
     _check("x", x, x.device)
     _check("packed", packed, x.device)
@@ -416,6 +418,12 @@ def linear_packed_forward(x, packed, out_features, bias=None, row_mask=None, hea
     if packed.dtype != torch.uint8 or packed.numel() == 0 or packed.numel() != lib.linear_hip_packed_weight_bytes(n, k):
         raise RuntimeError("linear_packed_forward: `packed` does not belong to a [%d, %d] weight" % (n, k))
     hm = int(head_major_rows)
+    if x_add is not None:
+        _check("x_add", x_add, x.device)
+        if x_add.dtype != torch.float32 or x_add.shape != x.shape:
+            raise RuntimeError("linear_packed_forward: x_add must be float32 with the shape of x")
+    if hm and (x_add is not None or relu):
+        raise RuntimeError("linear_packed_forward: head-major output does not combine with x_add / relu")
     if hm:
         if x.dim() != 3 or x.shape[1] != hm or n % 32:
             raise RuntimeError("linear_packed_forward: head-major output needs x [N, S, in_features] and out_features % 32 == 0")
@@ -428,8 +436,45 @@ def linear_packed_forward(x, packed, out_features, bias=None, row_mask=None, hea
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         if hm:
             rc = lib.linear_hip_packed_hm_f32(x.data_ptr(), packed.data_ptr(), b_ptr, m_ptr, rows, k, n, hm, out.data_ptr(), st)
+        elif x_add is not None or relu:
+            rc = lib.linear_hip_packed_ex_f32(x.data_ptr(), x_add.data_ptr() if x_add is not None else None, packed.data_ptr(),
+                                              b_ptr, m_ptr, rows, k, n, int(bool(relu)), out.data_ptr(), st)
         else:
             rc = lib.linear_hip_packed_f32(x.data_ptr(), packed.data_ptr(), b_ptr, m_ptr, rows, k, n, out.data_ptr(), st)
+    if rc != 0:
+        _raise(rc)
+    return out
+
+
+def add_layernorm_supported(x, normalized_shape):
+    return (x.is_cuda and x.dtype == torch.float32 and len(normalized_shape) == 1 and x.shape[-1] == normalized_shape[0]
+            and x.shape[-1] % 4 == 0 and x.shape[-1] <= 4096)
+
+
+def add_layernorm(x, residual, weight, bias, eps):
+    """LayerNorm(x + residual) over the last dimension in one pass (include/layernorm_hip.h); residual may be None."""
+    lib = _lib.load()
+    _check("x", x, x.device)
+    for name, t in (("residual", residual), ("weight", weight), ("bias", bias)):
+        if t is not None:
+            _check(name, t, x.device)
+            if t.dtype != torch.float32:
+                raise RuntimeError("%s must be float32" % name)
+    if x.dtype != torch.float32:
+        raise RuntimeError("x must be float32")
+    d = x.shape[-1]
+    if residual is not None and residual.shape != x.shape:
+        raise RuntimeError("add_layernorm: residual must have the shape of x")
+    for name, t in (("weight", weight), ("bias", bias)):
+        if t is not None and t.shape != (d,):
+            raise RuntimeError("add_layernorm: %s must be [features]" % name)
+    out = torch.empty_like(x)
+    rows = x.numel() // d if d else 0
+    with torch.cuda.device(x.device):
+        rc = lib.add_layernorm_hip_f32(x.data_ptr(), residual.data_ptr() if residual is not None else None,
+                                       weight.data_ptr() if weight is not None else None,
+                                       bias.data_ptr() if bias is not None else None, float(eps), rows, d, out.data_ptr(),
+                                       ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     if rc != 0:
         _raise(rc)
     return out

@@ -77,11 +77,13 @@ class MSDeformAttn(nn.Module):
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or lin.weight.requires_grad)
         return self.fast_linear and not needs_grad and x.is_contiguous() and MSDA.linear_packed_supported(x, lin.weight)
 
-    def _project(self, lin, x, row_mask=None, head_major_rows=0):
+    def _project(self, lin, x, row_mask=None, head_major_rows=0, x_add=None, relu=False):
         """`lin(x)` (then zero the rows where row_mask is True).  Inference on the GPU: include/linear_hip.h from a
         packed copy of the weight cached on the Linear and rebuilt when the parameter changes; head_major_rows = S
-        writes the result as [N, heads, S, 32] (only requested when _fast_ok)."""
-        if self._fast_ok(lin, x):
+        writes the result as [N, heads, S, 32] (only requested when _fast_ok); x_add is added to the input while it is
+        loaded, relu applied in the epilogue."""
+        if self._fast_ok(lin, x) and (x_add is None or (x_add.is_contiguous() and x_add.shape == x.shape
+                                                        and x_add.dtype == x.dtype and not x_add.requires_grad)):
             w = lin.weight
             key = (w.data_ptr(), w._version, str(w.device))
             cache = lin.__dict__.get("_msda_packed")
@@ -89,9 +91,11 @@ class MSDeformAttn(nn.Module):
                 cache = (key, MSDA.linear_pack_weight(w.detach().contiguous()))
                 lin.__dict__["_msda_packed"] = cache
             mask = row_mask.contiguous() if row_mask is not None else None
-            return MSDA.linear_packed_forward(x, cache[1], w.shape[0], lin.bias, mask, head_major_rows)
+            return MSDA.linear_packed_forward(x, cache[1], w.shape[0], lin.bias, mask, head_major_rows, x_add, relu)
         assert head_major_rows == 0
-        y = lin(x)
+        y = lin(x if x_add is None else x + x_add)
+        if relu:
+            y = F.relu(y)
         if row_mask is not None:
             y = y.masked_fill(row_mask[..., None], float(0))
         return y
@@ -121,10 +125,12 @@ class MSDeformAttn(nn.Module):
 
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
-                input_padding_mask=None):
+                input_padding_mask=None, query_pos=None):
         """query (N, Lq, C); reference_points (N, Lq, n_levels, 2|4) in [0,1]; input_flatten (N, sum HW, C);
         input_spatial_shapes (n_levels, 2) int64 (H, W); input_level_start_index (n_levels,) int64;
-        input_padding_mask (N, sum HW) bool, True = padding.  Returns (N, Lq, C)."""
+        input_padding_mask (N, sum HW) bool, True = padding.  Returns (N, Lq, C).
+        query_pos (extension, optional): the layer input is query + query_pos (`with_pos_embed`), added inside the
+        projections instead of by a separate kernel."""
         N, Len_in, _ = input_flatten.shape
         assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == Len_in
         if reference_points.shape[-1] not in (2, 4):
@@ -141,8 +147,8 @@ class MSDeformAttn(nn.Module):
         value = self._project(self.value_proj, input_flatten, input_padding_mask, Len_in if head_major else 0)
         if not head_major:
             value = value.view(N, Len_in, self.n_heads, head_dim)
-        offsets = self._project(self.sampling_offsets, query)        # (N, Lq, M*L*P*2)
-        logits = self._project(self.attention_weights, query)        # (N, Lq, M*L*P)
+        offsets = self._project(self.sampling_offsets, query, x_add=query_pos)        # (N, Lq, M*L*P*2)
+        logits = self._project(self.attention_weights, query, x_add=query_pos)        # (N, Lq, M*L*P)
 
         if head_major:
             sampled = MSDA.ms_deform_attn_forward_fused(value, input_spatial_shapes, input_level_start_index,
