@@ -51,19 +51,19 @@ linear_packed(const float* __restrict__ x, const float* __restrict__ x2, const u
   // t / 16 + 16 r, so a wave instruction reads 4 rows x 256 contiguous bytes (full lines)
   const int s_piece = tid & 15, s_row0 = tid >> 4;
   constexpr int kRows = BM / 16, TI = BM / 64;   // rows staged per thread; 32-row MFMA tiles per wave
-  const float* a_ptr[kRows];
+  long long a_off[kRows];                               // element offset of this thread's piece in row r (x and x2 alike)
 #pragma unroll
   for (int r = 0; r < kRows; ++r) {
     long long mr = m0 + s_row0 + 16 * r;
     mr = mr < M ? mr : M - 1;
-    a_ptr[r] = x + mr * K + s_piece * 4;
+    a_off[r] = mr * K + s_piece * 4;
   }
   f32x4 a_reg[kRows];
   auto load_step = [&](int st) {
 #pragma unroll
     for (int r = 0; r < kRows; ++r) {
-      a_reg[r] = *reinterpret_cast<const f32x4*>(a_ptr[r] + st * kStepK);
-      if (x2) a_reg[r] += *reinterpret_cast<const f32x4*>(a_ptr[r] + (x2 - x) + st * kStepK);   // input = x + x2
+      a_reg[r] = *reinterpret_cast<const f32x4*>(x + a_off[r] + st * kStepK);
+      if (x2) a_reg[r] += *reinterpret_cast<const f32x4*>(x2 + a_off[r] + st * kStepK);   // input = x + x2
     }
   };
   auto store_step = [&](int buf) {
