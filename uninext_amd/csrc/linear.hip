@@ -35,7 +35,7 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4v& hi, u32x4v& 
   }
 }
 
-template <int TJ, int BM>
+template <int TJ, int BM, bool ADD>   // ADD: the input is x + x2
 __global__ void __launch_bounds__(kThreads, 2)
 linear_packed(const float* __restrict__ x, const float* __restrict__ x2, const uint32_t* __restrict__ packed,
               const float* __restrict__ bias, const uint8_t* __restrict__ row_mask, long long M, int K, int N, int n_pad,
@@ -63,7 +63,7 @@ linear_packed(const float* __restrict__ x, const float* __restrict__ x2, const u
 #pragma unroll
     for (int r = 0; r < kRows; ++r) {
       a_reg[r] = *reinterpret_cast<const f32x4*>(x + a_off[r] + st * kStepK);
-      if (x2) a_reg[r] += *reinterpret_cast<const f32x4*>(x2 + a_off[r] + st * kStepK);   // input = x + x2
+      if constexpr (ADD) a_reg[r] += *reinterpret_cast<const f32x4*>(x2 + a_off[r] + st * kStepK);
     }
   };
   auto store_step = [&](int buf) {
@@ -243,11 +243,15 @@ static int linear_impl(const float* x, const float* x2, const void* packed, cons
   // 128 columns per workgroup unless that leaves CUs idle
   if (out_features > 64 && mt * ((out_features + 127) / 128) >= 512) {
     dim3 grid((unsigned)mt, (unsigned)((out_features + 127) / 128));
-    hipLaunchKernelGGL((linear::linear_packed<2, BM>), grid, dim3(linear::kThreads), 0, st, x, x2, pk, bias, row_mask, rows,
+    if (x2) hipLaunchKernelGGL((linear::linear_packed<2, BM, true>), grid, dim3(linear::kThreads), 0, st, x, x2, pk, bias, row_mask, rows,
+                       in_features, out_features, n_pad, hm_rows, act, out);
+    else hipLaunchKernelGGL((linear::linear_packed<2, BM, false>), grid, dim3(linear::kThreads), 0, st, x, x2, pk, bias, row_mask, rows,
                        in_features, out_features, n_pad, hm_rows, act, out);
   } else {
     dim3 grid((unsigned)mt, (unsigned)((out_features + 63) / 64));
-    hipLaunchKernelGGL((linear::linear_packed<1, BM>), grid, dim3(linear::kThreads), 0, st, x, x2, pk, bias, row_mask, rows,
+    if (x2) hipLaunchKernelGGL((linear::linear_packed<1, BM, true>), grid, dim3(linear::kThreads), 0, st, x, x2, pk, bias, row_mask, rows,
+                       in_features, out_features, n_pad, hm_rows, act, out);
+    else hipLaunchKernelGGL((linear::linear_packed<1, BM, false>), grid, dim3(linear::kThreads), 0, st, x, x2, pk, bias, row_mask, rows,
                        in_features, out_features, n_pad, hm_rows, act, out);
   }
   const hipError_t e = hipGetLastError();
