@@ -35,7 +35,10 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4v& hi, u32x4v& 
   }
 }
 
-template <int TJ, int BM, bool ADD>   // ADD: the input is x + x2
+// WM: waves along the rows (1 or 2).  A wave owning ONE 32-row tile re-loads 2 KB of weight fragments per 3 MFMAs, more
+// than the CU's 64 B/clk L1 path delivers per MFMA slot; with WM = 1 every wave spans the tile's 64 rows (two row tiles
+// per weight fragment) and a quarter of its columns.
+template <int TJ, int BM, bool ADD, int WM>   // ADD: the input is x + x2
 __global__ void __launch_bounds__(kThreads, 2)
 linear_packed(const float* __restrict__ x, const float* __restrict__ x2, const uint32_t* __restrict__ packed,
               const float* __restrict__ bias, const uint8_t* __restrict__ row_mask, long long M, int K, int N, int n_pad,
@@ -50,7 +53,9 @@ linear_packed(const float* __restrict__ x, const float* __restrict__ x2, const u
   // staging: a step is 128 rows x 64 k = 16 pieces of 16 bytes per row; lane t % 16 takes piece t % 16 of rows
   // t / 16 + 16 r, so a wave instruction reads 4 rows x 256 contiguous bytes (full lines)
   const int s_piece = tid & 15, s_row0 = tid >> 4;
-  constexpr int kRows = BM / 16, TI = BM / 64;   // rows staged per thread; 32-row MFMA tiles per wave
+  constexpr int kRows = BM / 16;                  // rows staged per thread
+  constexpr int WN = 4 / WM, TI = BM / (32 * WM), WJ = 2 * TJ / WN;   // per wave: TI row tiles x WJ column tiles
+  static_assert(TI >= 1 && WJ >= 1, "wave layout");
   long long a_off[kRows];                               // element offset of this thread's piece in row r (x and x2 alike)
 #pragma unroll
   for (int r = 0; r < kRows; ++r) {
@@ -84,27 +89,27 @@ linear_packed(const float* __restrict__ x, const float* __restrict__ x2, const u
     }
   };
 
-  const int wm = (wv >> 1) * (BM / 2), wn = (wv & 1) * 32 * TJ;
+  const int wm = (wv / WN) * (BM / WM), wn = (wv % WN) * 32 * WJ;
   const int r32 = lane & 31, half = lane >> 5;
   const uint32_t* w_lane = packed + (long long)(n0 + wn + r32) * 8 + half * 4;
   const long long chunk_stride = (long long)2 * n_pad * 8, part_stride = (long long)n_pad * 8;
   const int nchunks = K / kChunk, nsteps = K / kStepK;
-  struct WFrag { u32x4v hi[TJ], lo[TJ]; };
+  struct WFrag { u32x4v hi[WJ], lo[WJ]; };
   auto load_w = [&](int ch, WFrag& f) {
     const int cc = ch < nchunks ? ch : nchunks - 1;
     const uint32_t* p = w_lane + cc * chunk_stride;
 #pragma unroll
-    for (int jn = 0; jn < TJ; ++jn) {
+    for (int jn = 0; jn < WJ; ++jn) {
       f.hi[jn] = *reinterpret_cast<const u32x4v*>(p + jn * 32 * 8);
       f.lo[jn] = *reinterpret_cast<const u32x4v*>(p + part_stride + jn * 32 * 8);
     }
   };
 
-  f32x16 acc[TI][TJ];
+  f32x16 acc[TI][WJ];
 #pragma unroll
   for (int i = 0; i < TI; ++i)
 #pragma unroll
-    for (int jn = 0; jn < TJ; ++jn)
+    for (int jn = 0; jn < WJ; ++jn)
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[i][jn][v] = 0.f;
 
@@ -114,7 +119,7 @@ linear_packed(const float* __restrict__ x, const float* __restrict__ x2, const u
       const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(&As[buf][0][cc][wm + i * 32 + r32][half * 4]));
       const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(&As[buf][1][cc][wm + i * 32 + r32][half * 4]));
 #pragma unroll
-      for (int jn = 0; jn < TJ; ++jn) {   // rows = x rows, columns = output features; small terms first
+      for (int jn = 0; jn < WJ; ++jn) {   // rows = x rows, columns = output features; small terms first
         const bf16x8 wh = __builtin_bit_cast(bf16x8, wf.hi[jn]), wl = __builtin_bit_cast(bf16x8, wf.lo[jn]);
         acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl, acc[i][jn], 0, 0, 0);
         acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh, acc[i][jn], 0, 0, 0);
@@ -162,7 +167,7 @@ linear_packed(const float* __restrict__ x, const float* __restrict__ x2, const u
       }
     }
 #pragma unroll
-    for (int jn = 0; jn < TJ; ++jn) {
+    for (int jn = 0; jn < WJ; ++jn) {
       const int n = n0 + wn + jn * 32 + r32;
       const float bv = (bias && n < N) ? bias[n] : 0.f;
 #pragma unroll
@@ -243,15 +248,15 @@ static int linear_impl(const float* x, const float* x2, const void* packed, cons
   // 128 columns per workgroup unless that leaves CUs idle
   if (out_features > 64 && mt * ((out_features + 127) / 128) >= 512) {
     dim3 grid((unsigned)mt, (unsigned)((out_features + 127) / 128));
-    if (x2) hipLaunchKernelGGL((linear::linear_packed<2, BM, true>), grid, dim3(linear::kThreads), 0, st, x, x2, pk, bias, row_mask, rows,
+    if (x2) hipLaunchKernelGGL((linear::linear_packed<2, BM, true, 1>), grid, dim3(linear::kThreads), 0, st, x, x2, pk, bias, row_mask, rows,
                        in_features, out_features, n_pad, hm_rows, act, out);
-    else hipLaunchKernelGGL((linear::linear_packed<2, BM, false>), grid, dim3(linear::kThreads), 0, st, x, x2, pk, bias, row_mask, rows,
+    else hipLaunchKernelGGL((linear::linear_packed<2, BM, false, 1>), grid, dim3(linear::kThreads), 0, st, x, x2, pk, bias, row_mask, rows,
                        in_features, out_features, n_pad, hm_rows, act, out);
   } else {
     dim3 grid((unsigned)mt, (unsigned)((out_features + 63) / 64));
-    if (x2) hipLaunchKernelGGL((linear::linear_packed<1, BM, true>), grid, dim3(linear::kThreads), 0, st, x, x2, pk, bias, row_mask, rows,
+    if (x2) hipLaunchKernelGGL((linear::linear_packed<1, BM, true, 2>), grid, dim3(linear::kThreads), 0, st, x, x2, pk, bias, row_mask, rows,
                        in_features, out_features, n_pad, hm_rows, act, out);
-    else hipLaunchKernelGGL((linear::linear_packed<1, BM, false>), grid, dim3(linear::kThreads), 0, st, x, x2, pk, bias, row_mask, rows,
+    else hipLaunchKernelGGL((linear::linear_packed<1, BM, false, 2>), grid, dim3(linear::kThreads), 0, st, x, x2, pk, bias, row_mask, rows,
                        in_features, out_features, n_pad, hm_rows, act, out);
   }
   const hipError_t e = hipGetLastError();
