@@ -198,14 +198,17 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4v& hi, u32x4v& 
   }
 }
 
-template <int KS, bool NHWC, int TJ, int BM>
+// WM: waves along the patches (1 or 2); with WM = 1 a wave spans the tile's 64 patches, so a weight fragment feeds two
+// row tiles (a wave with one row tile re-loads weights faster than the 64 B/clk L1 path delivers them).
+template <int KS, bool NHWC, int TJ, int BM, int WM>
 __global__ void __launch_bounds__(kThreads, 2)
 patch_embed_packed(const float* __restrict__ x, const uint32_t* __restrict__ packed, const float* __restrict__ bias, Geom g,
                    int e_pad, float* __restrict__ out) {
   constexpr int VW = KS >= 4 ? 4 : 2;                 // floats per load (a kx run)
   constexpr int PP = kChunk / VW;                     // pieces per (patch, chunk)
   constexpr int kItems = kStepChunks * BM * PP / kThreads;   // staging items per thread and step
-  constexpr int TI = BM / 64;
+  constexpr int WN = 4 / WM, TI = BM / (32 * WM), WJ = 2 * TJ / WN;   // per wave: TI row tiles x WJ column tiles
+  static_assert(TI >= 1 && WJ >= 1, "wave layout");
   // [buffer][hi / lo][chunk][patch (+1 pad row: staggers the banks of the staging stores)][16 bf16]
   __shared__ __attribute__((aligned(16))) uint32_t As[2][2][kStepChunks][BM + 1][8];
 
@@ -262,28 +265,28 @@ patch_embed_packed(const float* __restrict__ x, const uint32_t* __restrict__ pac
     }
   };
 
-  const int wm = (wv >> 1) * (BM / 2), wn = (wv & 1) * 32 * TJ;
+  const int wm = (wv / WN) * (BM / WM), wn = (wv % WN) * 32 * WJ;
   const int r32 = lane & 31, half = lane >> 5;
   const int nb = n0 + wn + r32;
   const uint32_t* w_lane = packed + (int64_t)nb * 8 + half * 4;
   const int64_t chunk_stride = (int64_t)2 * e_pad * 8, part_stride = (int64_t)e_pad * 8;
   const int nchunks = g.K / kChunk, nsteps = g.K / kStepK;
-  struct WFrag { u32x4v hi[TJ], lo[TJ]; };
+  struct WFrag { u32x4v hi[WJ], lo[WJ]; };
   auto load_w = [&](int ch, WFrag& f) {
     const int cc = ch < nchunks ? ch : nchunks - 1;
     const uint32_t* p = w_lane + cc * chunk_stride;
 #pragma unroll
-    for (int jn = 0; jn < TJ; ++jn) {
+    for (int jn = 0; jn < WJ; ++jn) {
       f.hi[jn] = *reinterpret_cast<const u32x4v*>(p + jn * 32 * 8);
       f.lo[jn] = *reinterpret_cast<const u32x4v*>(p + part_stride + jn * 32 * 8);
     }
   };
 
-  f32x16 acc[TI][TJ];
+  f32x16 acc[TI][WJ];
 #pragma unroll
   for (int i = 0; i < TI; ++i)
 #pragma unroll
-    for (int jn = 0; jn < TJ; ++jn)
+    for (int jn = 0; jn < WJ; ++jn)
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[i][jn][v] = 0.f;
 
@@ -293,7 +296,7 @@ patch_embed_packed(const float* __restrict__ x, const uint32_t* __restrict__ pac
       const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(&As[buf][0][cc][wm + i * 32 + r32][half * 4]));
       const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(&As[buf][1][cc][wm + i * 32 + r32][half * 4]));
 #pragma unroll
-      for (int jn = 0; jn < TJ; ++jn) {
+      for (int jn = 0; jn < WJ; ++jn) {
         const bf16x8 wh = __builtin_bit_cast(bf16x8, wf.hi[jn]), wl = __builtin_bit_cast(bf16x8, wf.lo[jn]);
         if constexpr (NHWC) {
           acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl, acc[i][jn], 0, 0, 0);
@@ -330,7 +333,7 @@ patch_embed_packed(const float* __restrict__ x, const uint32_t* __restrict__ pac
 #pragma unroll
   for (int i = 0; i < TI; ++i)
 #pragma unroll
-    for (int jn = 0; jn < TJ; ++jn) {
+    for (int jn = 0; jn < WJ; ++jn) {
       if constexpr (NHWC) {
         const int n = n0 + wn + jn * 32 + r32;
         const float bv = (bias && n < g.E) ? bias[n] : 0.f;
@@ -378,12 +381,12 @@ static int launch_packed_bm(const float* x, const uint32_t* packed, const float*
   const bool wide = g.E > 64 && mt * ((g.E + 127) / 128) >= 512;   // 128 channels per workgroup unless CUs would idle
   if (wide) {
     dim3 grid((unsigned)mt, (unsigned)((g.E + 127) / 128));
-    if (channels_last) hipLaunchKernelGGL((patch_embed_packed<KS, true, 2, BM>), grid, dim3(kThreads), 0, stream, x, packed, bias, g, e_pad, out);
-    else hipLaunchKernelGGL((patch_embed_packed<KS, false, 2, BM>), grid, dim3(kThreads), 0, stream, x, packed, bias, g, e_pad, out);
+    if (channels_last) hipLaunchKernelGGL((patch_embed_packed<KS, true, 2, BM, (BM == 64 ? 1 : 2)>), grid, dim3(kThreads), 0, stream, x, packed, bias, g, e_pad, out);
+    else hipLaunchKernelGGL((patch_embed_packed<KS, false, 2, BM, (BM == 64 ? 1 : 2)>), grid, dim3(kThreads), 0, stream, x, packed, bias, g, e_pad, out);
   } else {
     dim3 grid((unsigned)mt, (unsigned)((g.E + 63) / 64));
-    if (channels_last) hipLaunchKernelGGL((patch_embed_packed<KS, true, 1, BM>), grid, dim3(kThreads), 0, stream, x, packed, bias, g, e_pad, out);
-    else hipLaunchKernelGGL((patch_embed_packed<KS, false, 1, BM>), grid, dim3(kThreads), 0, stream, x, packed, bias, g, e_pad, out);
+    if (channels_last) hipLaunchKernelGGL((patch_embed_packed<KS, true, 1, BM, 2>), grid, dim3(kThreads), 0, stream, x, packed, bias, g, e_pad, out);
+    else hipLaunchKernelGGL((patch_embed_packed<KS, false, 1, BM, 2>), grid, dim3(kThreads), 0, stream, x, packed, bias, g, e_pad, out);
   }
   return (int)hipGetLastError();
 }
