@@ -478,3 +478,58 @@ def add_layernorm(x, residual, weight, bias, eps):
     if rc != 0:
         _raise(rc)
     return out
+
+
+def lsap_batch(costs, check=True):
+    """Linear sum assignment of each 2-d fp32 GPU cost matrix in `costs` (row-major views with any row stride, e.g.
+    column slices of one big matrix) on the device, with SciPy's result index for index (include/lsap_hip.h).
+    Returns a list of (row_ind, col_ind) int64 GPU tensors.  check=True synchronises once at the end and raises
+    ValueError where SciPy would (NaN / -inf entries, infeasible matrix); check=False never leaves the stream."""
+    lib = _lib.load()
+    if not costs:
+        return []
+    dev = costs[0].device
+    for c in costs:
+        if not (c.is_cuda and c.device == dev and c.dtype == torch.float32 and c.dim() == 2):
+            raise RuntimeError("lsap_batch: expected 2-d float32 tensors on one GPU")
+        if c.numel() and (c.stride(1) != 1 or c.stride(0) < c.shape[1]):
+            raise RuntimeError("lsap_batch: rows must be contiguous (row stride >= cols, column stride 1)")
+    results, keep = [], []
+    status = torch.full((len(costs),), -1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for lo in range(0, len(costs), _lib.LSAP_MAX_BATCH):
+            chunk = costs[lo:lo + _lib.LSAP_MAX_BATCH]
+            n = len(chunk)
+            P, LL, I = ctypes.c_void_p * n, ctypes.c_longlong * n, ctypes.c_int * n
+            rows = [c.shape[0] for c in chunk]
+            cols = [c.shape[1] for c in chunk]
+            outs = [(torch.empty(min(r, k), dtype=torch.int64, device=dev), torch.empty(min(r, k), dtype=torch.int64, device=dev))
+                    for r, k in zip(rows, cols)]
+            ws = [torch.empty(lib.lsap_hip_workspace_bytes(r, k), dtype=torch.uint8, device=dev) for r, k in zip(rows, cols)]
+            keep.append(ws)
+            rc = lib.lsap_hip_batch_f32(
+                n, P(*[c.data_ptr() if c.numel() else None for c in chunk]),
+                LL(*[c.stride(0) if c.numel() else max(k, 1) for c, k in zip(chunk, cols)]), I(*rows), I(*cols),
+                P(*[o[0].data_ptr() if o[0].numel() else None for o in outs]),
+                P(*[o[1].data_ptr() if o[1].numel() else None for o in outs]), P(*[w.data_ptr() for w in ws]),
+                P(*[status[lo + k:].data_ptr() for k in range(n)]), stream)
+            if rc != 0:
+                _raise(rc)
+            results += outs
+    if check:
+        st = status.cpu().tolist()      # also keeps the workspaces alive until the kernels are done
+        if any(s == 1 for s in st):
+            raise ValueError("matrix contains invalid numeric entries")
+        if any(s == 2 for s in st):
+            raise ValueError("cost matrix is infeasible")
+    else:
+        for ws in keep:                 # the caching allocator may hand the workspace out again: tie it to the stream
+            for w in ws:
+                w.record_stream(torch.cuda.current_stream())
+    return results
+
+
+def lsap(cost, check=True):
+    """scipy.optimize.linear_sum_assignment(cost) for one 2-d fp32 GPU matrix, on the device."""
+    return lsap_batch([cost], check)[0]

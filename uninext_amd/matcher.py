@@ -88,6 +88,7 @@ class HungarianMatcherVL(nn.Module):
     """
 
     batched_topk = True   # dynamic-k selection without a host sync per ground-truth box (same indices; see the tests)
+    device_lsap = True    # GPU inputs: solve the assignment on the device (include/lsap_hip.h) instead of C.cpu() + SciPy
 
     def __init__(self, cost_class: float = 1, cost_bbox: float = 1, cost_giou: float = 1, cost_mask: float = 1):
         super().__init__()
@@ -108,9 +109,15 @@ class HungarianMatcherVL(nn.Module):
         cost_bbox = torch.cdist(boxes, tgt_boxes, p=1)
         cost_giou = -generalized_box_iou(box_cxcywh_to_xyxy(boxes), box_cxcywh_to_xyxy(tgt_boxes))
         cost = self.cost_bbox * cost_bbox + self.cost_class * cost_class + self.cost_giou * cost_giou
+        sizes = [len(t["boxes"]) for t in targets]
+        if self.device_lsap and cost.is_cuda and cost.dtype == torch.float32:
+            # SciPy's algorithm with SciPy's tie rules on the GPU: no copy of the [Q, G] matrix, no host solve; only the
+            # min(Q, G) index pairs come back (the reference returns CPU index tensors, matcher.py:503)
+            from . import ext as _ext
+            blocks = [blk[b] for b, blk in enumerate(cost.view(bs, num_queries, -1).split(sizes, -1))]
+            return [(i.cpu(), j.cpu()) for i, j in _ext.lsap_batch(blocks, check=True)]
         cost = cost.view(bs, num_queries, -1).cpu()   # the one device->host copy; LSAP runs on the host
 
-        sizes = [len(t["boxes"]) for t in targets]
         result = []
         for b, block in enumerate(cost.split(sizes, -1)):
             rows, cols = linear_sum_assignment(block[b])
