@@ -37,6 +37,17 @@ def main():
             ext.patch_embed_packed_forward(img, packed, 1280, 16, b, True)
         for _ in range(3):
             ext.patch_embed_forward(img, w, b, channels_last=True)
+        # the layer's projections and the FFN (include/linear_hip.h), 44 446 rows
+        xl = r(2, 22223, 256)
+        for n in (256, 1024):
+            w, b = r(n, 256) / 16.0, r(n)
+            packed = ext.linear_pack_weight(w)
+            for _ in range(5):
+                ext.linear_packed_forward(xl, packed, n, b, relu=(n == 1024))
+        xh, w, b = r(2, 22223, 1024), r(256, 1024) / 32.0, r(256)
+        packed = ext.linear_pack_weight(w)
+        for _ in range(5):
+            ext.linear_packed_forward(xh, packed, 256, b)
         # ConvNeXt-L downsample 2
         xd, w, b = r(2, 384, 100, 166), r(768, 384, 2, 2) / 39.2, r(768)
         packed = ext.patch_embed_pack_weight(w)
