@@ -72,6 +72,26 @@ class MSDeformAttn(nn.Module):
         xavier_uniform_(self.output_proj.weight.data)
         constant_(self.output_proj.bias.data, 0.0)
 
+    # -- argument check of :93 without a device->host sync per call -----------------------------------------
+    _shape_checks = {}
+
+    @classmethod
+    def _check_shapes(cls, spatial_shapes, len_in):
+        """`assert (H * W).sum() == Len_in` (ops/modules/ms_deform_attn.py:93).  On a GPU tensor the comparison is a
+        host sync; it is done once per (tensor, version, Len_in) and skipped while a HIP graph is being captured."""
+        if spatial_shapes.is_cuda:
+            if torch.cuda.is_current_stream_capturing():
+                return
+            key = (spatial_shapes.data_ptr(), spatial_shapes._version, str(spatial_shapes.device), int(len_in))
+            if cls._shape_checks.get(key):
+                return
+            if len(cls._shape_checks) > 64:
+                cls._shape_checks.clear()
+            assert (spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum() == len_in
+            cls._shape_checks[key] = True
+            return
+        assert (spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum() == len_in
+
     # -- projections ------------------------------------------------------------------------------------------
     def _fast_ok(self, lin, x):
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or lin.weight.requires_grad)
@@ -132,7 +152,7 @@ class MSDeformAttn(nn.Module):
         query_pos (extension, optional): the layer input is query + query_pos (`with_pos_embed`), added inside the
         projections instead of by a separate kernel."""
         N, Len_in, _ = input_flatten.shape
-        assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == Len_in
+        self._check_shapes(input_spatial_shapes, Len_in)
         if reference_points.shape[-1] not in (2, 4):
             raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(
                 reference_points.shape[-1]))
