@@ -115,3 +115,37 @@ def test_layer_full_size_routes_agree(dev):
         finally:
             MSDeformAttn.fast_linear = True
     assert float((fast - want).abs().max()) < 1e-4 * max(1.0, float(want.abs().max()))
+
+
+def test_layer_is_hip_graph_capturable(dev):
+    """Inference through the layer only enqueues kernels (no sync, no host-side data dependence): capture it once,
+    replay it on new inputs, compare with eager execution."""
+    from uninext_amd import workloads
+    from uninext_amd.modules import DeformableTransformerEncoderLayer
+    torch.manual_seed(13)
+    levels = ((32, 40), (16, 20), (8, 10), (4, 5))
+    S = sum(h * w for h, w in levels)
+    layer = DeformableTransformerEncoderLayer().to(dev).eval()
+    with torch.no_grad():
+        layer.self_attn.sampling_offsets.weight.normal_(0, 0.02)
+        layer.self_attn.attention_weights.weight.normal_(0, 0.1)
+    src, pos = torch.randn(2, S, 256, device=dev), torch.randn(2, S, 256, device=dev) * 0.3
+    ref = workloads.encoder_reference_points(levels, dev)[None, :, None, :].expand(2, S, 4, 2).contiguous()
+    sh, lsi = workloads.level_tensors(levels, dev)
+    mask = torch.zeros(2, S, dtype=torch.bool, device=dev)
+    mask[0, :50] = True
+    with torch.no_grad():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            layer(src, pos, ref, sh, lsi, mask)                      # warm-up: packs the weights, checks the shapes
+        torch.cuda.current_stream().wait_stream(side)
+        static_src = src.clone()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_out = layer(static_src, pos, ref, sh, lsi, mask)
+        new_src = torch.randn_like(src)
+        static_src.copy_(new_src)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(static_out, layer(new_src, pos, ref, sh, lsi, mask))
