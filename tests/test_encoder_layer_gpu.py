@@ -148,4 +148,7 @@ def test_layer_is_hip_graph_capturable(dev):
         static_src.copy_(new_src)
         graph.replay()
         torch.cuda.synchronize()
-        assert torch.equal(static_out, layer(new_src, pos, ref, sh, lsi, mask))
+        same = torch.equal(static_out, layer(new_src, pos, ref, sh, lsi, mask))
+        torch.cuda.synchronize()
+        del graph                                   # release the captured graph while the runtime is fully alive
+    assert same
