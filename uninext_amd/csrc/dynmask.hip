@@ -118,7 +118,7 @@ dynmask_fwd(const float* __restrict__ feats, const float* __restrict__ inst_xy, 
 // align_corners=True (source coordinate = i / f), replicate-pad f/2 on the top/left, crop to (f*h, f*w).
 // One workgroup per (image, band of kRows output rows): row index arithmetic is uniform, the source rows stay in
 // L1, stores are coalesced.
-constexpr int kRows = 8;
+constexpr int kRows = 32;
 __global__ void __launch_bounds__(kThreads)
 aligned_bilinear_kernel(const float* __restrict__ in, int h, int w, int factor, float* __restrict__ out) {
   const int oh = factor * h, ow = factor * w;
@@ -128,24 +128,35 @@ aligned_bilinear_kernel(const float* __restrict__ in, int h, int w, int factor, 
   const float inv = 1.0f / (float)factor;
   const float* src = in + (size_t)img * h * w;
   float* dst = out + (size_t)img * oh * ow;
-  for (int yy = 0; yy < kRows; ++yy) {
+  // the band is walked as one flat list of x-pairs (full lanes whatever the row length; 8-byte stores)
+  const int ow2 = (ow + 1) / 2;
+  const int rows = min(kRows, oh - y_first);
+  for (int p = threadIdx.x; p < rows * ow2; p += kThreads) {
+    const int yy = p / ow2, x = 2 * (p - yy * ow2);
     const int y = y_first + yy;
-    if (y >= oh) break;
     const int iy = max(y - factor / 2, 0);
     const float sy = (float)iy * inv;
     const int y0 = (int)sy;
     const float fy = sy - (float)y0;
     const float* r0 = src + (size_t)min(y0, h - 1) * w;
     const float* r1 = src + (size_t)min(y0 + 1, h - 1) * w;
-    float* o = dst + (size_t)y * ow;
-    for (int x = threadIdx.x; x < ow; x += kThreads) {
-      const int ix = max(x - factor / 2, 0);
+    float res[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int ix = max(x + e - factor / 2, 0);
       const float sx = (float)ix * inv;
       const int x0 = (int)sx;
       const float fx = sx - (float)x0;
       const int x0c = min(x0, w - 1), x1c = min(x0 + 1, w - 1);
       const float top = r0[x0c] + (r0[x1c] - r0[x0c]) * fx, bot = r1[x0c] + (r1[x1c] - r1[x0c]) * fx;
-      __builtin_nontemporal_store(top + (bot - top) * fy, o + x);
+      res[e] = top + (bot - top) * fy;
+    }
+    float* o = dst + (size_t)y * ow + x;
+    if (x + 1 < ow && (((size_t)y * ow + x) & 1) == 0 && ((reinterpret_cast<uintptr_t>(dst) & 7) == 0)) {
+      __builtin_nontemporal_store(msda::f32x2{res[0], res[1]}, reinterpret_cast<msda::f32x2*>(o));
+    } else {
+      __builtin_nontemporal_store(res[0], o);
+      if (x + 1 < ow) __builtin_nontemporal_store(res[1], o + 1);
     }
   }
 }
