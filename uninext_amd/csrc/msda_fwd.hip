@@ -563,17 +563,20 @@ msda_fwd_lg3(const float* __restrict__ value, const int64_t* __restrict__ shapes
     };
     const float mx = gmax(fmaxf(at0, at1));
     const float e0 = __expf(at0 - mx), e1 = __expf(at1 - mx);
-    const float inv = 1.0f / group8_add(e0 + e1);
+    // this prologue runs in all 16 waves of the workgroup at once, before any gather is issued: every instruction
+    // here is on the critical path of the CU.  v_rcp_f32 (1 ulp) instead of IEEE divisions: the sampling location
+    // moves by < 1e-6 of a pixel, the weights by 1 ulp
+    const float inv = __builtin_amdgcn_rcpf(group8_add(e0 + e1));
     at0 = e0 * inv;
     at1 = e1 * inv;
     const float* rp = ref_points + ((int64_t)b * d.Lq + (live ? q : 0)) * LPT / P * REFD;
     const int l0 = j / P, l1 = 2 + j / P;               // levels of samples j and 8 + j (L = P = 4)
     if constexpr (REFD == 2) {
       const float2 r0 = *reinterpret_cast<const float2*>(rp + l0 * 2), r1 = *reinterpret_cast<const float2*>(rp + l1 * 2);
-      lc0.x = r0.x + lc0.x / (float)smp_W[j];
-      lc0.y = r0.y + lc0.y / (float)smp_H[j];
-      lc1.x = r1.x + lc1.x / (float)smp_W[8 + j];
-      lc1.y = r1.y + lc1.y / (float)smp_H[8 + j];
+      lc0.x = fmaf(lc0.x, __builtin_amdgcn_rcpf((float)smp_W[j]), r0.x);
+      lc0.y = fmaf(lc0.y, __builtin_amdgcn_rcpf((float)smp_H[j]), r0.y);
+      lc1.x = fmaf(lc1.x, __builtin_amdgcn_rcpf((float)smp_W[8 + j]), r1.x);
+      lc1.y = fmaf(lc1.y, __builtin_amdgcn_rcpf((float)smp_H[8 + j]), r1.y);
     } else {
       const float4 r0 = *reinterpret_cast<const float4*>(rp + l0 * 4), r1 = *reinterpret_cast<const float4*>(rp + l1 * 4);
       lc0.x = r0.x + lc0.x / (float)P * r0.z * 0.5f;
