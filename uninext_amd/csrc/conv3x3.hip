@@ -317,7 +317,9 @@ static int launch_bf16x3(const float* in, const float* w, const float* bias, con
 constexpr int kTH = 8, kTW = 16, kHaloW = kTW + 2, kHaloPx = (kTH + 2) * kHaloW;   // 180
 constexpr int kChunk = 16;
 
-template <int TJ, bool RELU>
+// WM: waves along the pixel rows (2: a wave owns 4 rows = 2 sub-tiles and 32 TJ channels; 1: a wave owns all 8 rows =
+// 4 sub-tiles and 16 TJ channels, so a weight fragment feeds twice as many MFMAs -- half the weight traffic through L1).
+template <int TJ, bool RELU, int WM>
 __global__ void __launch_bounds__(kThreads, 2)
 conv3x3_packed(const float* __restrict__ in, const uint32_t* __restrict__ packed, const float* __restrict__ bias, Geom g,
                int tiles_x, int tiles_per_image, int cout_pad, float* __restrict__ out) {
@@ -363,33 +365,35 @@ conv3x3_packed(const float* __restrict__ in, const uint32_t* __restrict__ packed
   };
 
   // ---- MFMA fragments ----------------------------------------------------------------------------------------
-  const int wm = wv >> 1, wn = wv & 1;                 // pixel rows 4 wm .. 4 wm + 3, channels 32 TJ wn ..
+  constexpr int WN = 4 / WM, TI = 4 / WM, WJ = 2 * TJ / WN;   // per wave: TI 32-pixel sub-tiles x WJ 32-channel tiles
+  static_assert(WJ >= 1, "wave layout");
+  const int wm = wv / WN, wn = wv % WN;
   const int r32 = lane & 31, half = lane >> 5;
   // LDS word offset of this lane's A fragment for sub-tile i, tap (0, 0): pixel (4 wm + 2 i + r32 / 16, r32 % 16)
-  int a_off[2];
+  int a_off[TI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) a_off[i] = ((wm * 4 + i * 2 + (r32 >> 4)) * kHaloW + (r32 & 15)) * 8 + half * 4;
+  for (int i = 0; i < TI; ++i) a_off[i] = ((wm * 2 * TI + i * 2 + (r32 >> 4)) * kHaloW + (r32 & 15)) * 8 + half * 4;
   // packed weights: u32 index of (flat tap ft, part, channel n, half) = ((ft * 2 + part) * cout_pad + n) * 8 + half * 4
-  const int nb = n0 + wn * 32 * TJ + r32;
+  const int nb = n0 + wn * 32 * WJ + r32;
   const uint32_t* w_lane = packed + (int64_t)nb * 8 + half * 4;
   const int64_t tap_stride = (int64_t)2 * cout_pad * 8, part_stride = (int64_t)cout_pad * 8;
   const int nchunks = g.Cin / kChunk, ntaps = nchunks * 9;
-  struct WFrag { u32x4v hi[TJ], lo[TJ]; };
+  struct WFrag { u32x4v hi[WJ], lo[WJ]; };
   auto load_w = [&](int ft, WFrag& f) {
     const int fc = ft < ntaps ? ft : ntaps - 1;        // past the end: re-read the last tap (never used)
     const uint32_t* p = w_lane + fc * tap_stride;
 #pragma unroll
-    for (int jn = 0; jn < TJ; ++jn) {
+    for (int jn = 0; jn < WJ; ++jn) {
       f.hi[jn] = *reinterpret_cast<const u32x4v*>(p + jn * 32 * 8);
       f.lo[jn] = *reinterpret_cast<const u32x4v*>(p + part_stride + jn * 32 * 8);
     }
   };
 
-  f32x16 acc[2][TJ];
+  f32x16 acc[TI][WJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
-    for (int jn = 0; jn < TJ; ++jn)
+    for (int jn = 0; jn < WJ; ++jn)
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[i][jn][v] = 0.f;
 
@@ -403,11 +407,11 @@ conv3x3_packed(const float* __restrict__ in, const uint32_t* __restrict__ packed
   auto tap_mfma = [&](int buf, int tap, const WFrag& wf) {   // tap compile-time after unrolling
     const int toff = ((tap / 3) * kHaloW + (tap % 3)) * 8;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TI; ++i) {
       const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(&As[buf][0][0][0] + a_off[i] + toff));
       const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(&As[buf][1][0][0] + a_off[i] + toff));
 #pragma unroll
-      for (int jn = 0; jn < TJ; ++jn) {                // small terms first
+      for (int jn = 0; jn < WJ; ++jn) {                // small terms first
         acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf.lo[jn]), ah, acc[i][jn], 0, 0, 0);
         acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf.hi[jn]), al, acc[i][jn], 0, 0, 0);
         acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf.hi[jn]), ah, acc[i][jn], 0, 0, 0);
@@ -433,14 +437,14 @@ conv3x3_packed(const float* __restrict__ in, const uint32_t* __restrict__ packed
 
   // ---- epilogue: accumulator register v of lane l is (channel row 8 (v / 4) + 4 (l / 32) + v % 4, pixel l % 32) ------
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int gy = ty0 + wm * 4 + i * 2 + (r32 >> 4), gx = tx0 + (r32 & 15);
+  for (int i = 0; i < TI; ++i) {
+    const int gy = ty0 + wm * 2 * TI + i * 2 + (r32 >> 4), gx = tx0 + (r32 & 15);
     const bool pix_ok = gy < g.H && gx < g.W;
 #pragma unroll
-    for (int jn = 0; jn < TJ; ++jn)
+    for (int jn = 0; jn < WJ; ++jn)
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
-        const int n = n0 + wn * 32 * TJ + jn * 32 + 8 * (v / 4) + 4 * half + (v % 4);
+        const int n = n0 + wn * 32 * WJ + jn * 32 + 8 * (v / 4) + 4 * half + (v % 4);
         if (pix_ok && n < g.Cout) {
           float r = acc[i][jn][v] + (bias ? bias[n] : 0.f);
           if (RELU) r = fmaxf(r, 0.f);
@@ -556,12 +560,12 @@ int conv3x3_hip_packed_f32(const float* in, const void* packed, const float* bia
   if (forced_tj == 2) wide = cout > 64;
   if (wide) {
     dim3 grid((unsigned)tiles, (unsigned)((cout + 127) / 128));
-    if (relu) hipLaunchKernelGGL((conv3x3::conv3x3_packed<2, true>), grid, dim3(conv3x3::kThreads), 0, st, in, pk, bias, g, tiles_x, tiles_x * tiles_y, cout_pad, out);
-    else hipLaunchKernelGGL((conv3x3::conv3x3_packed<2, false>), grid, dim3(conv3x3::kThreads), 0, st, in, pk, bias, g, tiles_x, tiles_x * tiles_y, cout_pad, out);
+    if (relu) hipLaunchKernelGGL((conv3x3::conv3x3_packed<2, true, 1>), grid, dim3(conv3x3::kThreads), 0, st, in, pk, bias, g, tiles_x, tiles_x * tiles_y, cout_pad, out);
+    else hipLaunchKernelGGL((conv3x3::conv3x3_packed<2, false, 1>), grid, dim3(conv3x3::kThreads), 0, st, in, pk, bias, g, tiles_x, tiles_x * tiles_y, cout_pad, out);
   } else {
     dim3 grid((unsigned)tiles, (unsigned)((cout + 63) / 64));
-    if (relu) hipLaunchKernelGGL((conv3x3::conv3x3_packed<1, true>), grid, dim3(conv3x3::kThreads), 0, st, in, pk, bias, g, tiles_x, tiles_x * tiles_y, cout_pad, out);
-    else hipLaunchKernelGGL((conv3x3::conv3x3_packed<1, false>), grid, dim3(conv3x3::kThreads), 0, st, in, pk, bias, g, tiles_x, tiles_x * tiles_y, cout_pad, out);
+    if (relu) hipLaunchKernelGGL((conv3x3::conv3x3_packed<1, true, 2>), grid, dim3(conv3x3::kThreads), 0, st, in, pk, bias, g, tiles_x, tiles_x * tiles_y, cout_pad, out);
+    else hipLaunchKernelGGL((conv3x3::conv3x3_packed<1, false, 2>), grid, dim3(conv3x3::kThreads), 0, st, in, pk, bias, g, tiles_x, tiles_x * tiles_y, cout_pad, out);
   }
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : dynmask_set_error((int)e, hipGetErrorString(e));
