@@ -54,6 +54,15 @@ int conv3x3_hip_pack_weight_f32(const float* weight, int cout, int cin, void* pa
 int conv3x3_hip_packed_f32(const float* in, const void* packed, const float* bias, int batch, int cin, int height,
                            int width, int cout, int relu, float* out, void* stream);
 
+/*
+ * out = skip + nearest-neighbour up-sampling of `low` to skip's size: the FPN-style merges of MaskHeadSmallConv.forward
+ * (`x[-2] + F.interpolate(fused_x, size=..., mode="nearest")`, ddetrs_dn.py:1001,1012) in one pass instead of an
+ * interpolate kernel, an add kernel and an intermediate.  skip / out [batch, channels, height, width], low
+ * [batch, channels, low_h, low_w]; source index = min(floor(dst * (low / size)), low - 1) in fp32, as PyTorch computes it.
+ */
+int upsample_add_hip_f32(const float* skip, const float* low, int batch, int channels, int height, int width, int low_h,
+                         int low_w, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,7 +60,7 @@ def test_initialisation_follows_reference():
 def test_header_symbols_are_exported():
     from uninext_amd import _lib
     text = open(os.path.join(ROOT, "include", "conv3x3_hip.h")).read()
-    declared = set(re.findall(r"\b(conv3x3_hip_\w+)\s*\(", text))
+    declared = set(re.findall(r"\b((?:conv3x3|upsample_add)_hip_\w+)\s*\(", text))
     assert declared == set(_lib.CONV3X3_EXPORTS)
     lib = _lib.load()
     for sym in _lib.CONV3X3_EXPORTS:

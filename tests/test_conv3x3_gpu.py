@@ -139,6 +139,17 @@ def test_split_precision_error_level(dev):
     assert float((np.abs(out - ref) / scale).max()) < 1e-4
 
 
+@pytest.mark.parametrize("H,W,h,w", [(50, 84, 25, 42), (100, 167, 50, 84), (13, 18, 7, 9), (7, 9, 4, 5), (5, 5, 5, 5), (9, 31, 2, 3)])
+def test_upsample_add_equals_torch(H, W, h, w, dev):
+    from uninext_amd import ext
+    g = torch.Generator().manual_seed(H * W)
+    skip, low = torch.randn(2, 6, H, W, generator=g).to(dev), torch.randn(2, 6, h, w, generator=g).to(dev)
+    want = skip + torch.nn.functional.interpolate(low, size=(H, W), mode="nearest")
+    assert torch.equal(ext.upsample_add(skip, low), want)             # same source pixel, one fp32 add: bitwise
+    with pytest.raises(RuntimeError, match="expected float32"):
+        ext.upsample_add(skip, low[:, :3].contiguous())
+
+
 def test_errors(dev):
     from uninext_amd import ext
     x = torch.randn(1, 8, 4, 4, device=dev)

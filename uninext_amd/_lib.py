@@ -24,7 +24,7 @@ LAYERNORM_EXPORTS = ("add_layernorm_hip_f32",)                                 #
 LSAP_EXPORTS = ("lsap_hip_workspace_bytes", "lsap_hip_f32", "lsap_hip_batch_f32")   # include/lsap_hip.h
 LSAP_MAX_BATCH = 32
 CONV3X3_EXPORTS = ("conv3x3_hip_f32", "conv3x3_hip_packed_weight_bytes", "conv3x3_hip_pack_weight_f32",
-                   "conv3x3_hip_packed_f32")                                   # include/conv3x3_hip.h
+                   "conv3x3_hip_packed_f32", "upsample_add_hip_f32")           # include/conv3x3_hip.h
 
 _lib = None
 
@@ -77,6 +77,7 @@ def load():
     lib.conv3x3_hip_packed_weight_bytes.argtypes, lib.conv3x3_hip_packed_weight_bytes.restype = [i, i], ctypes.c_size_t
     lib.conv3x3_hip_pack_weight_f32.argtypes, lib.conv3x3_hip_pack_weight_f32.restype = [p, i, i, p, p], i
     lib.conv3x3_hip_packed_f32.argtypes, lib.conv3x3_hip_packed_f32.restype = [p, p, p, i, i, i, i, i, i, p, p], i
+    lib.upsample_add_hip_f32.argtypes, lib.upsample_add_hip_f32.restype = [p, p, i, i, i, i, i, i, p, p], i
     lib.msda_hip_set_variant.argtypes, lib.msda_hip_set_variant.restype = [i, i], i
     lib.msda_hip_get_variant.argtypes, lib.msda_hip_get_variant.restype = [i], i
     lib.msda_hip_variant_name.argtypes, lib.msda_hip_variant_name.restype = [i, i], s

@@ -482,6 +482,29 @@ static int launch_tile(const float* in, const float* w, const float* bias, const
   return (int)hipGetLastError();
 }
 
+// out = skip + nearest(low): one thread per 4 consecutive x of a row (16-byte loads / stores where the row allows it)
+__global__ void __launch_bounds__(256)
+upsample_add_kernel(const float* __restrict__ skip, const float* __restrict__ low, int planes, int H, int W, int h, int w,
+                    float* __restrict__ out) {
+  const int wq = (W + 3) / 4;
+  const long long total = (long long)planes * H * wq;
+  const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int xq = (int)(idx % wq);
+    const long long row = idx / wq;               // plane * H + y
+    const int y = (int)(row % H);
+    const long long plane = row / H;
+    const int ys = min((int)floorf((float)y * sy), h - 1);
+    const float* lrow = low + (plane * h + ys) * w;
+    const long long base = row * W + 4 * xq;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int x = 4 * xq + e;
+      if (x < W) out[base + e] = skip[base + e] + lrow[min((int)floorf((float)x * sx), w - 1)];
+    }
+  }
+}
+
 }  // namespace conv3x3
 
 extern "C" {
@@ -567,6 +590,24 @@ int conv3x3_hip_packed_f32(const float* in, const void* packed, const float* bia
     if (relu) hipLaunchKernelGGL((conv3x3::conv3x3_packed<1, true, 2>), grid, dim3(conv3x3::kThreads), 0, st, in, pk, bias, g, tiles_x, tiles_x * tiles_y, cout_pad, out);
     else hipLaunchKernelGGL((conv3x3::conv3x3_packed<1, false, 2>), grid, dim3(conv3x3::kThreads), 0, st, in, pk, bias, g, tiles_x, tiles_x * tiles_y, cout_pad, out);
   }
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : dynmask_set_error((int)e, hipGetErrorString(e));
+}
+
+
+int upsample_add_hip_f32(const float* skip, const float* low, int batch, int channels, int height, int width, int low_h,
+                         int low_w, float* out, void* stream) {
+  if (batch < 0 || channels <= 0 || height <= 0 || width <= 0 || low_h <= 0 || low_w <= 0)
+    return dynmask_set_error(CONV3X3_ERR_BAD_DIMS, "upsample_add: bad dimensions");
+  const long long planes = (long long)batch * channels;
+  if (planes == 0) return 0;
+  if (planes * height >= (1ll << 31)) return dynmask_set_error(CONV3X3_ERR_BAD_DIMS, "upsample_add: problem too large");
+  if (!skip || !low || !out) return dynmask_set_error(CONV3X3_ERR_NULL_POINTER, "upsample_add: null pointer argument");
+  const long long total = planes * height * ((width + 3) / 4);
+  long long blocks = (total + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(conv3x3::upsample_add_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, skip, low,
+                     (int)planes, height, width, low_h, low_w, out);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : dynmask_set_error((int)e, hipGetErrorString(e));
 }

@@ -533,3 +533,21 @@ def lsap_batch(costs, check=True):
 def lsap(cost, check=True):
     """scipy.optimize.linear_sum_assignment(cost) for one 2-d fp32 GPU matrix, on the device."""
     return lsap_batch([cost], check)[0]
+
+
+def upsample_add(skip, low):
+    """`skip + F.interpolate(low, size=skip.shape[-2:], mode="nearest")` in one pass (include/conv3x3_hip.h)."""
+    lib = _lib.load()
+    _check("skip", skip, skip.device)
+    _check("low", low, skip.device)
+    if skip.dtype != torch.float32 or low.dtype != torch.float32 or skip.dim() != 4 or low.dim() != 4 \
+            or skip.shape[:2] != low.shape[:2]:
+        raise RuntimeError("upsample_add: expected float32 skip [B, C, H, W] and low [B, C, h, w]")
+    B, C, H, W = skip.shape
+    out = torch.empty_like(skip)
+    with torch.cuda.device(skip.device):
+        rc = lib.upsample_add_hip_f32(skip.data_ptr(), low.data_ptr(), B, C, H, W, low.shape[2], low.shape[3],
+                                      out.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc != 0:
+        _raise(rc)
+    return out

@@ -179,6 +179,10 @@ class MaskHeadSmallConv(torch.nn.Module):
             skip = (cur + skip) / 2
         if fused is None:
             return skip
+        needs_grad = torch.is_grad_enabled() and (skip.requires_grad or fused.requires_grad)
+        if not needs_grad and skip.is_cuda and skip.dtype == torch.float32 and fused.dtype == torch.float32 \
+                and fused.is_contiguous():
+            return _ext.upsample_add(skip.contiguous(), fused)      # one pass: no interpolate output, no separate add
         return skip + F.interpolate(fused, size=skip.shape[-2:], mode="nearest")
 
     def forward(self, x, fpns):
