@@ -56,6 +56,17 @@ int linear_hip_packed_ex_f32(const float* x, const float* x_add, const void* pac
                              const uint8_t* row_mask, long long rows, int in_features, int out_features, int activation,
                              float* out, void* stream);
 
+/*
+ * Linear followed by the residual add and LayerNorm of the transformer layer, in the Linear's epilogue:
+ *     out[m, :] = LayerNorm(residual[m, :] + bias + x[m, :] W^T) * gamma + beta
+ * (`src = src + dropout(linear2(...)); src = norm2(src)` and the attention's output_proj + norm1,
+ * deformable_transformer_dino.py:355-357, 363-365).  out_features must be 256 (a workgroup holds whole rows);
+ * `residual`, `gamma`, `beta`, `bias` may be NULL.
+ */
+int linear_hip_packed_ln_f32(const float* x, const void* packed, const float* bias, const float* residual,
+                             const float* gamma, const float* beta, float eps, long long rows, int in_features,
+                             int out_features, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -158,6 +158,27 @@ def test_fused_lg3_and_head_major_vs_oracle(ref_dim, dev):
     assert hm.shape == (N, 8, S, 32) and torch.equal(hm, rm.view(N, S, 8, 32).permute(0, 2, 1, 3))
 
 
+@pytest.mark.parametrize("rows,k", [(1, 64), (63, 256), (64, 256), (1000, 256), (333, 1024)])
+@pytest.mark.parametrize("with_res", [True, False])
+def test_linear_layernorm_epilogue(rows, k, with_res, dev):
+    from uninext_amd import ext
+    g = torch.Generator().manual_seed(rows + k)
+    x = torch.randn(rows, k, generator=g).to(dev)
+    w = (torch.randn(256, k, generator=g) / k ** 0.5).to(dev)
+    b, gm, bt = (torch.randn(256, generator=g).to(dev) for _ in range(3))
+    res = (torch.randn(rows, 256, generator=g) * 2).to(dev) if with_res else None
+    packed = ext.linear_pack_weight(w)
+    got = ext.linear_packed_ln(x, packed, b, res, gm, bt, 1e-5)
+    y = torch.nn.functional.linear(x.double(), w.double(), b.double()) + (res.double() if with_res else 0)
+    want = torch.nn.functional.layer_norm(y, (256,), gm.double(), bt.double(), 1e-5)
+    assert float((got.double() - want).abs().max()) < 1e-4 * max(1.0, float(want.abs().max()))
+    plain = ext.linear_packed_ln(x, packed, None, res, None, None, 1e-5)
+    y = torch.nn.functional.linear(x.double(), w.double()) + (res.double() if with_res else 0)
+    assert float((plain.double() - torch.nn.functional.layer_norm(y, (256,), None, None, 1e-5)).abs().max()) < 1e-4
+    with pytest.raises(RuntimeError, match="packed copy"):
+        ext.linear_packed_ln(x, ext.linear_pack_weight(torch.randn(128, k, device=dev)), None, None, None, None, 1e-5)
+
+
 def test_errors(dev):
     from uninext_amd import ext
     with pytest.raises(RuntimeError, match="multiple of 64"):

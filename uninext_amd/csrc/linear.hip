@@ -38,11 +38,23 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4v& hi, u32x4v& 
 // WM: waves along the rows (1 or 2).  A wave owning ONE 32-row tile re-loads 2 KB of weight fragments per 3 MFMAs, more
 // than the CU's 64 B/clk L1 path delivers per MFMA slot; with WM = 1 every wave spans the tile's 64 rows (two row tiles
 // per weight fragment) and a quarter of its columns.
-template <int TJ, int BM, bool ADD, int WM>   // ADD: the input is x + x2
+struct LnArgs {   // LayerNorm(out + residual) over the N columns in the epilogue (LN kernels only: N == 64 TJ)
+  const float* residual;
+  const float* gamma;
+  const float* beta;
+  float eps;
+};
+
+template <int CTRL>
+__device__ __forceinline__ float msda_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
+template <int TJ, int BM, bool ADD, int WM, bool LN = false>   // ADD: the input is x + x2
 __global__ void __launch_bounds__(kThreads, 2)
 linear_packed(const float* __restrict__ x, const float* __restrict__ x2, const uint32_t* __restrict__ packed,
               const float* __restrict__ bias, const uint8_t* __restrict__ row_mask, long long M, int K, int N, int n_pad,
-              int hm_rows, int act, float* __restrict__ out) {
+              int hm_rows, int act, float* __restrict__ out, LnArgs ln = LnArgs{nullptr, nullptr, nullptr, 0.f}) {
   // [buffer][hi / lo][chunk][row (+1 pad row per chunk: staggers the banks of the staging stores)][16 bf16]
   __shared__ __attribute__((aligned(16))) uint32_t As[2][2][kStepChunks][BM + 1][8];
 
@@ -150,6 +162,77 @@ linear_packed(const float* __restrict__ x, const float* __restrict__ x2, const u
     __syncthreads();
   }
 
+  if constexpr (LN) {
+    // ---- out = LayerNorm(acc + bias + residual) * gamma + beta: the workgroup holds whole rows (N == 64 TJ columns,
+    // a quarter per wave).  Two-pass statistics like add_layernorm: row sums are reduced over the 32 lanes of a
+    // half-wave with DPP + one xor-16 exchange, then over the four waves through LDS (the operand tile is dead by now).
+    static_assert(WM == 1 && BM == 64, "LayerNorm epilogue: every wave spans the 64 rows");
+    float* red = reinterpret_cast<float*>(&As[0][0][0][0][0]);   // [4 waves][64 rows] partial sums, then [64] totals at +256
+    auto sum32 = [](float v) {
+      v += msda_dpp<0xB1>(v); v += msda_dpp<0x4E>(v); v += msda_dpp<0x141>(v); v += msda_dpp<0x140>(v);
+      return v + __shfl_xor(v, 16, 64);
+    };
+    float val[TI][WJ][16];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int jn = 0; jn < WJ; ++jn) {
+        const int n = wn + jn * 32 + r32;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          long long m = m0 + wm + i * 32 + 8 * (v / 4) + 4 * half + (v % 4);
+          m = m < M ? m : M - 1;
+          val[i][jn][v] = acc[i][jn][v] + bv + (ln.residual ? ln.residual[m * N + n] : 0.f);
+        }
+      }
+    float stat[TI][16];
+    auto reduce_rows = [&](bool centred, const float (&mean)[TI][16]) {
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          float p = 0.f;
+#pragma unroll
+          for (int jn = 0; jn < WJ; ++jn) {
+            const float t = centred ? val[i][jn][v] - mean[i][v] : val[i][jn][v];
+            p += centred ? t * t : t;
+          }
+          p = sum32(p);
+          if (r32 == 0) red[wv * 64 + i * 32 + 8 * (v / 4) + 4 * half + (v % 4)] = p;
+        }
+      __syncthreads();
+      if (tid < 64) red[256 + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) stat[i][v] = red[256 + i * 32 + 8 * (v / 4) + 4 * half + (v % 4)];
+      __syncthreads();   // `red` is rewritten by the next pass
+    };
+    float mean[TI][16];
+    reduce_rows(false, mean);
+    const float inv_n = 1.0f / (float)N;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) mean[i][v] = stat[i][v] * inv_n;
+    reduce_rows(true, mean);
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int jn = 0; jn < WJ; ++jn) {
+        const int n = wn + jn * 32 + r32;
+        const float gmm = ln.gamma ? ln.gamma[n] : 1.f, bt = ln.beta ? ln.beta[n] : 0.f;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const long long m = m0 + wm + i * 32 + 8 * (v / 4) + 4 * half + (v % 4);
+          const float rstd = rsqrtf(stat[i][v] * inv_n + ln.eps);
+          if (m < M) out[m * N + n] = (val[i][jn][v] - mean[i][v]) * rstd * gmm + bt;
+        }
+      }
+    return;
+  }
   // epilogue: accumulator register v of lane l is (row 8 (v / 4) + 4 (l / 32) + v % 4, column l % 32)
 #pragma unroll
   for (int i = 0; i < TI; ++i) {
@@ -275,6 +358,24 @@ int linear_hip_packed_hm_f32(const float* x, const void* packed, const float* bi
   if (rows_per_image <= 0 || out_features % 32 != 0 || (rows >= 0 && rows % rows_per_image != 0))
     return dynmask_set_error(LINEAR_ERR_BAD_DIMS, "linear (head-major): out_features must be a multiple of 32 and rows a multiple of rows_per_image");
   return linear_impl(x, nullptr, packed, bias, row_mask, rows, in_features, out_features, rows_per_image, 0, out, stream);
+}
+
+int linear_hip_packed_ln_f32(const float* x, const void* packed, const float* bias, const float* residual,
+                             const float* gamma, const float* beta, float eps, long long rows, int in_features,
+                             int out_features, float* out, void* stream) {
+  if (rows < 0 || in_features <= 0 || out_features <= 0)
+    return dynmask_set_error(LINEAR_ERR_BAD_DIMS, "linear: bad dimensions");
+  if (in_features % linear::kStepK != 0 || out_features != 256)
+    return dynmask_set_error(LINEAR_ERR_UNSUPPORTED, "linear + LayerNorm: in_features must be a multiple of 64 and out_features 256");
+  if (rows == 0) return 0;
+  const long long mt = (rows + 63) / 64;
+  if (mt >= (1ll << 31)) return dynmask_set_error(LINEAR_ERR_BAD_DIMS, "linear: problem too large");
+  if (!x || !packed || !out) return dynmask_set_error(LINEAR_ERR_NULL_POINTER, "linear: null pointer argument");
+  hipLaunchKernelGGL((linear::linear_packed<4, 64, false, 1, true>), dim3((unsigned)mt, 1u), dim3(linear::kThreads), 0,
+                     (hipStream_t)stream, x, nullptr, static_cast<const uint32_t*>(packed), bias, nullptr, rows, in_features,
+                     out_features, linear::n_padded(out_features), 0, 0, out, linear::LnArgs{residual, gamma, beta, eps});
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : dynmask_set_error((int)e, hipGetErrorString(e));
 }
 
 int linear_hip_packed_ex_f32(const float* x, const float* x_add, const void* packed, const float* bias,

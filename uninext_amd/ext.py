@@ -551,3 +551,35 @@ def upsample_add(skip, low):
     if rc != 0:
         _raise(rc)
     return out
+
+
+def linear_packed_ln_supported(x, weight, norm_shape):
+    return linear_packed_supported(x, weight) and weight.shape[0] == 256 and tuple(norm_shape) == (256,)
+
+
+def linear_packed_ln(x, packed, bias, residual, ln_weight, ln_bias, eps):
+    """LayerNorm(residual + F.linear(x, W, bias)) * ln_weight + ln_bias with the add and the normalisation in the
+    Linear's epilogue (include/linear_hip.h; out_features == 256).  x [..., in_features] -> [..., 256]."""
+    lib = _lib.load()
+    _check("x", x, x.device)
+    _check("packed", packed, x.device)
+    k, n = x.shape[-1], 256
+    rows = x.numel() // k if k else 0
+    for name, t, shape in (("bias", bias, (n,)), ("ln_weight", ln_weight, (n,)), ("ln_bias", ln_bias, (n,)),
+                           ("residual", residual, x.shape[:-1] + (n,))):
+        if t is not None:
+            _check(name, t, x.device)
+            if t.dtype != torch.float32 or tuple(t.shape) != tuple(shape):
+                raise RuntimeError("linear_packed_ln: %s must be float32 %s" % (name, tuple(shape)))
+    if x.dtype != torch.float32 or packed.dtype != torch.uint8 or packed.numel() != lib.linear_hip_packed_weight_bytes(n, k) \
+            or packed.numel() == 0:
+        raise RuntimeError("linear_packed_ln: expected float32 x and the packed copy of a [256, %d] weight" % k)
+    out = torch.empty(x.shape[:-1] + (n,), dtype=torch.float32, device=x.device)
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    with torch.cuda.device(x.device):
+        rc = lib.linear_hip_packed_ln_f32(x.data_ptr(), packed.data_ptr(), ptr(bias), ptr(residual), ptr(ln_weight),
+                                          ptr(ln_bias), float(eps), rows, k, n, out.data_ptr(),
+                                          ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc != 0:
+        _raise(rc)
+    return out

@@ -6,7 +6,8 @@ unchanged) and forward.  When autograd records (training) the layer is the refer
 around `MSDeformAttn`.  At inference on the GPU (dropout is the identity):
 
   * `with_pos_embed(src, pos)` is folded into the operand load of the sampling_offsets / attention_weights projections;
-  * `src + dropout(src2)` followed by `normN` is one kernel (include/layernorm_hip.h);
+  * `src + dropout(src2)` followed by `normN` runs in the epilogue of the Linear that produced src2 (output_proj,
+    linear2: `linear_hip_packed_ln_f32`; a stand-alone add + LayerNorm kernel, include/layernorm_hip.h, covers other widths);
   * `linear1` + ReLU and `linear2` run on include/linear_hip.h (split-bf16 MFMA, packed weights, ReLU in the epilogue).
 """
 import torch
@@ -71,10 +72,9 @@ class DeformableTransformerEncoderLayer(nn.Module):
             src = self.norm1(src + self.dropout1(src2))
             return self.forward_ffn(src)
         attn = self.self_attn
-        src2 = attn(src, reference_points, src, spatial_shapes, level_start_index, padding_mask, query_pos=pos)
-        src = self._add_norm(src2, src, self.norm1)
+        src = attn(src, reference_points, src, spatial_shapes, level_start_index, padding_mask, query_pos=pos,
+                   residual_norm=(src, self.norm1))                       # norm1(src + attention) in output_proj's epilogue
         hidden = attn._project(self.linear1, src, relu=self._relu)
         if not self._relu:
             hidden = self.activation(hidden)
-        src2 = attn._project(self.linear2, hidden)
-        return self._add_norm(src2, src, self.norm2)
+        return attn._project_norm(self.linear2, hidden, src, self.norm2)  # norm2(src + ffn) in linear2's epilogue

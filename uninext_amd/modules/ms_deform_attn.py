@@ -97,6 +97,24 @@ class MSDeformAttn(nn.Module):
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or lin.weight.requires_grad)
         return self.fast_linear and not needs_grad and x.is_contiguous() and MSDA.linear_packed_supported(x, lin.weight)
 
+    def _packed(self, lin):
+        """Packed copy of lin.weight (include/linear_hip.h), cached on the Linear, rebuilt when the parameter changes."""
+        w = lin.weight
+        key = (w.data_ptr(), w._version, str(w.device))
+        cache = lin.__dict__.get("_msda_packed")
+        if cache is None or cache[0] != key:
+            cache = (key, MSDA.linear_pack_weight(w.detach().contiguous()))
+            lin.__dict__["_msda_packed"] = cache
+        return cache[1]
+
+    def _project_norm(self, lin, x, residual, norm):
+        """`norm(residual + lin(x))`: at inference the add and the LayerNorm run in the Linear's epilogue."""
+        if (self._fast_ok(lin, x) and norm.elementwise_affine and residual.is_contiguous()
+                and not (torch.is_grad_enabled() and residual.requires_grad)
+                and MSDA.linear_packed_ln_supported(x, lin.weight, norm.normalized_shape)):
+            return MSDA.linear_packed_ln(x, self._packed(lin), lin.bias, residual, norm.weight, norm.bias, norm.eps)
+        return norm(residual + self._project(lin, x))
+
     def _project(self, lin, x, row_mask=None, head_major_rows=0, x_add=None, relu=False):
         """`lin(x)` (then zero the rows where row_mask is True).  Inference on the GPU: include/linear_hip.h from a
         packed copy of the weight cached on the Linear and rebuilt when the parameter changes; head_major_rows = S
@@ -104,14 +122,9 @@ class MSDeformAttn(nn.Module):
         loaded, relu applied in the epilogue."""
         if self._fast_ok(lin, x) and (x_add is None or (x_add.is_contiguous() and x_add.shape == x.shape
                                                         and x_add.dtype == x.dtype and not x_add.requires_grad)):
-            w = lin.weight
-            key = (w.data_ptr(), w._version, str(w.device))
-            cache = lin.__dict__.get("_msda_packed")
-            if cache is None or cache[0] != key:
-                cache = (key, MSDA.linear_pack_weight(w.detach().contiguous()))
-                lin.__dict__["_msda_packed"] = cache
             mask = row_mask.contiguous() if row_mask is not None else None
-            return MSDA.linear_packed_forward(x, cache[1], w.shape[0], lin.bias, mask, head_major_rows, x_add, relu)
+            return MSDA.linear_packed_forward(x, self._packed(lin), lin.weight.shape[0], lin.bias, mask, head_major_rows,
+                                              x_add, relu)
         assert head_major_rows == 0
         y = lin(x if x_add is None else x + x_add)
         if relu:
@@ -145,12 +158,14 @@ class MSDeformAttn(nn.Module):
 
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
-                input_padding_mask=None, query_pos=None):
+                input_padding_mask=None, query_pos=None, residual_norm=None):
         """query (N, Lq, C); reference_points (N, Lq, n_levels, 2|4) in [0,1]; input_flatten (N, sum HW, C);
         input_spatial_shapes (n_levels, 2) int64 (H, W); input_level_start_index (n_levels,) int64;
         input_padding_mask (N, sum HW) bool, True = padding.  Returns (N, Lq, C).
         query_pos (extension, optional): the layer input is query + query_pos (`with_pos_embed`), added inside the
-        projections instead of by a separate kernel."""
+        projections instead of by a separate kernel.
+        residual_norm (extension, optional): (residual, LayerNorm) -- return norm(residual + output) with the add and
+        the normalisation in output_proj's epilogue."""
         N, Len_in, _ = input_flatten.shape
         self._check_shapes(input_spatial_shapes, Len_in)
         if reference_points.shape[-1] not in (2, 4):
@@ -180,4 +195,6 @@ class MSDeformAttn(nn.Module):
         else:
             sampled = self._sample_autograd(value, input_spatial_shapes, input_level_start_index, reference_points,
                                             offsets, logits)
+        if residual_norm is not None:
+            return self._project_norm(self.output_proj, sampled, residual_norm[0], residual_norm[1])
         return self._project(self.output_proj, sampled)
