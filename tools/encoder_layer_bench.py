@@ -99,7 +99,33 @@ def main():
     print("HIP-graph replay of this repo's layer (incl. the 45 MB input copy): %.1f us, max diff vs eager %.1e" % (t_graph, gerr))
     print("encoder layer (bs 2, %d tokens): this repo %.1f us | PyTorch ops + fused sampling %.1f us | reference data flow "
           "(PyTorch ops + operator) %.1f us | rel diff %.1e" % (S, t_fast, t_lib, t_ref, err))
-    print("six layers: %.2f ms vs %.2f ms" % (6e-3 * t_fast, 6e-3 * t_ref))
+    print("six layers (extrapolated): %.2f ms vs %.2f ms" % (6e-3 * t_fast, 6e-3 * t_ref))
+    # six DISTINCT layers back to back, as DeformableTransformerEncoder.forward runs them (deformable_transformer_dino.py)
+    layers = [layer] + [DeformableTransformerEncoderLayer().to(dev).eval() for _ in range(5)]
+    with torch.no_grad():
+        for l in layers[1:]:
+            l.self_attn.sampling_offsets.weight.normal_(0, 0.01)
+            l.self_attn.attention_weights.weight.normal_(0, 0.1)
+
+        def encoder(fast):
+            k = turn[0] % args.rotate
+            turn[0] += 1
+            out = srcs[k]
+            for l in layers:
+                if fast:
+                    out = l(out, pos, ref, sh, lsi, None)
+                else:
+                    src2 = l.self_attn(out + pos, ref, out, sh, lsi, None)
+                    out = l.norm1(out + src2)
+                    out = l.norm2(out + l.linear2(torch.relu(l.linear1(out))))
+            return out
+        t6 = timeit(lambda: encoder(True), max(args.reps // 2, 5))
+        MSDeformAttn.fast_linear = False
+        MSDeformAttn.fuse_prologue = False
+        t6_ref = timeit(lambda: encoder(False), max(args.reps // 2, 5))
+        MSDeformAttn.fast_linear = True
+        MSDeformAttn.fuse_prologue = True
+    print("six distinct layers back to back (measured): %.2f ms vs %.2f ms (PyTorch ops + operator)" % (t6 * 1e-3, t6_ref * 1e-3))
 
 
 if __name__ == "__main__":
