@@ -170,7 +170,7 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4v& hi, u32x4v& 
     const uint32_t al = __float_as_uint(v[2 * p] - __uint_as_float(ah));
     const uint32_t bl = __float_as_uint(v[2 * p + 1] - __uint_as_float(bh));
     hi[p] = (ah >> 16) | bh;                       // element 2p in the low half-word
-    lo[p] = (al >> 16) | (bl & 0xffff0000u);
+    lo[p] = ((al + 0x8000u) >> 16) | ((bl + 0x8000u) & 0xffff0000u);   // lo rounded to nearest
   }
 }
 
@@ -467,7 +467,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int cout, int ci
     const uint32_t lb = __float_as_uint(v - __uint_as_float(hb));
     const int64_t o = (((int64_t)(chunk * 9 + tap) * 2) * cout_pad + n) * kChunk + cl;
     packed[o] = (uint16_t)(hb >> 16);
-    packed[o + (int64_t)cout_pad * kChunk] = (uint16_t)(lb >> 16);
+    packed[o + (int64_t)cout_pad * kChunk] = (uint16_t)((lb + 0x8000u) >> 16);   // lo rounded to nearest
   }
 }
 

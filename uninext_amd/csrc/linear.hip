@@ -31,7 +31,7 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4v& hi, u32x4v& 
     const uint32_t al = __float_as_uint(v[2 * p] - __uint_as_float(ah));
     const uint32_t bl = __float_as_uint(v[2 * p + 1] - __uint_as_float(bh));
     hi[p] = (ah >> 16) | bh;
-    lo[p] = (al >> 16) | (bl & 0xffff0000u);
+    lo[p] = ((al + 0x8000u) >> 16) | ((bl + 0x8000u) & 0xffff0000u);   // lo rounded to nearest
   }
 }
 
@@ -94,7 +94,7 @@ linear_packed(const float* __restrict__ x, const float* __restrict__ x2, const u
         const uint32_t ah = __float_as_uint(fa) & 0xffff0000u, bh = __float_as_uint(fb) & 0xffff0000u;
         const uint32_t al = __float_as_uint(fa - __uint_as_float(ah)), bl = __float_as_uint(fb - __uint_as_float(bh));
         hi[p] = (ah >> 16) | bh;
-        lo[p] = (al >> 16) | (bl & 0xffff0000u);
+        lo[p] = ((al + 0x8000u) >> 16) | ((bl + 0x8000u) & 0xffff0000u);   // lo rounded to nearest
       }
       *reinterpret_cast<uint2*>(&As[buf][0][cc][s_row0 + 16 * r][w2]) = make_uint2(hi[0], hi[1]);
       *reinterpret_cast<uint2*>(&As[buf][1][cc][s_row0 + 16 * r][w2]) = make_uint2(lo[0], lo[1]);
@@ -282,7 +282,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int N, int K, in
     const uint32_t lb = __float_as_uint(v - __uint_as_float(hb));
     const long long o = ((long long)chunk * 2 * n_pad + n) * kChunk + kl;
     packed[o] = (uint16_t)(hb >> 16);
-    packed[o + (long long)n_pad * kChunk] = (uint16_t)(lb >> 16);
+    packed[o + (long long)n_pad * kChunk] = (uint16_t)((lb + 0x8000u) >> 16);   // lo rounded to nearest
   }
 }
 

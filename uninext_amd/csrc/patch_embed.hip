@@ -194,7 +194,7 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4v& hi, u32x4v& 
     const uint32_t al = __float_as_uint(v[2 * p] - __uint_as_float(ah));
     const uint32_t bl = __float_as_uint(v[2 * p + 1] - __uint_as_float(bh));
     hi[p] = (ah >> 16) | bh;
-    lo[p] = (al >> 16) | (bl & 0xffff0000u);
+    lo[p] = ((al + 0x8000u) >> 16) | ((bl + 0x8000u) & 0xffff0000u);   // lo rounded to nearest
   }
 }
 
@@ -253,7 +253,7 @@ patch_embed_packed(const float* __restrict__ x, const uint32_t* __restrict__ pac
         const uint32_t ah = __float_as_uint(fa) & 0xffff0000u, bh = __float_as_uint(fb) & 0xffff0000u;
         const uint32_t al = __float_as_uint(fa - __uint_as_float(ah)), bl = __float_as_uint(fb - __uint_as_float(bh));
         hi[p] = (ah >> 16) | bh;
-        lo[p] = (al >> 16) | (bl & 0xffff0000u);
+        lo[p] = ((al + 0x8000u) >> 16) | ((bl + 0x8000u) & 0xffff0000u);   // lo rounded to nearest
       }
       if constexpr (VW == 4) {
         *reinterpret_cast<uint2*>(&As[buf][0][cc][row][piece * 2]) = make_uint2(hi[0], hi[1]);
@@ -367,7 +367,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int E, int K, in
     const uint32_t lb = __float_as_uint(v - __uint_as_float(hb));
     const int64_t o = ((int64_t)chunk * 2 * e_pad + n) * kChunk + kl;
     packed[o] = (uint16_t)(hb >> 16);
-    packed[o + (int64_t)e_pad * kChunk] = (uint16_t)(lb >> 16);
+    packed[o + (int64_t)e_pad * kChunk] = (uint16_t)((lb + 0x8000u) >> 16);   // lo rounded to nearest
   }
 }
 
