@@ -512,13 +512,8 @@ bool tiled_backward_ok(const Dims& d) {
 int launch_backward_tiled(const float* grad_out, const float* value, const int64_t* shapes, const int64_t* lsi,
                           const float* loc, const float* attn, const Dims& d, float* grad_value, float* grad_loc,
                           float* grad_attn, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_tiled),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kBLdsBytes);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> lds_opted_in{0};
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(msda_bwd_tiled), kBLdsBytes, lds_opted_in)) return rc;
   // persistent grid: one 1024-thread workgroup per CU; a multiple of 8 so that item % M tracks blockIdx % 8
   hipLaunchKernelGGL(msda_bwd_tiled, dim3(256), dim3(kBT), kBLdsBytes, stream, grad_out, value, shapes, lsi, loc, attn,
                      d, grad_value, grad_loc, grad_attn);

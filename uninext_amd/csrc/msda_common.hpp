@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace msda {
 
 constexpr int kBlock = 256;      // 4 wave64 per workgroup
@@ -79,6 +81,21 @@ template <typename T>
 int launch_backward(int variant, const T* grad_out, const T* value, const int64_t* shapes, const int64_t* lsi,
                     const T* loc, const T* attn, const Dims& d, T* grad_value, T* grad_loc, T* grad_attn,
                     hipStream_t stream, const char** kernel_name);
+
+// More than 64 KiB of dynamic LDS needs an opt-in that HIP keeps PER DEVICE; `done` (one per kernel) remembers the
+// device ordinals already opted in, so a process that drives several GPUs gets the attribute on each of them.
+// Not a stream operation (safe under graph capture); racing threads at worst set the attribute twice.
+inline int ensure_dynamic_lds(const void* kernel, int bytes, std::atomic<uint64_t>& done) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return 0;
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return (int)e;
+  done.fetch_or(bit, std::memory_order_release);
+  return 0;
+}
 
 // Variant numbering shared with include/msda_hip.h.
 enum Variant { kAuto = 0, kGeneric = 1, kLaneGroup = 2, kTiled = 3, kTiledL0 = 4, kTiledL0Big = 5, kLaneGroupCL = 6,

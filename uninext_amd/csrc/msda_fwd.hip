@@ -672,13 +672,8 @@ template <int REFD>
 static int launch_lg3_t(const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc,
                         const float* attn, const float* ref_points, const Dims& d, int head_major, float* out,
                         hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_fwd_lg3<REFD>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kL3LdsBytes);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> lds_opted_in{0};
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(msda_fwd_lg3<REFD>), kL3LdsBytes, lds_opted_in)) return rc;
   constexpr int kPairs = kL3Threads / 8;
   dim3 grid((unsigned)(d.M * ((d.Lq + kPairs - 1) / kPairs)), (unsigned)d.N);
   hipLaunchKernelGGL(msda_fwd_lg3<REFD>, grid, dim3(kL3Threads), kL3LdsBytes, stream, value, shapes, lsi, loc, attn,
@@ -879,13 +874,8 @@ msda_fwd_lgp(const float* __restrict__ value, const int64_t* __restrict__ shapes
 
 static int launch_lgp(const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc,
                       const float* attn, const Dims& d, float* out, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_fwd_lgp),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kL3LdsBytes);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> lds_opted_in{0};
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(msda_fwd_lgp), kL3LdsBytes, lds_opted_in)) return rc;
   constexpr int kPairs = kL3Threads / 8;
   const int nchunks = (d.Lq + kPairs - 1) / kPairs;
   int K = (2 * 256) / (d.M * d.N);   // two resident workgroups per CU

@@ -449,13 +449,8 @@ bool tiled_forward_ok(const Dims& d) {
 template <int TH, int TW, int GL>
 static int launch_tiled(const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc,
                         const float* attn, const Dims& d, float* out, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in; idempotent, not a stream operation
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_fwd_tiled<TH, TW, GL>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kTiledLdsBytes);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> lds_opted_in{0};
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(msda_fwd_tiled<TH, TW, GL>), kTiledLdsBytes, lds_opted_in)) return rc;
   // persistent grid: 2 workgroups per CU on 256 CUs, a multiple of 8 so that item % M tracks blockIdx % 8
   hipLaunchKernelGGL((msda_fwd_tiled<TH, TW, GL>), dim3(512), dim3(kBlock), kTiledLdsBytes, stream, value, shapes, lsi,
                      loc, attn, d, out);
