@@ -1,13 +1,15 @@
 // Dynamic (per-instance) mask head of UNINEXT's CondInst branch for gfx950 -- see include/dynmask_hip.h.
 //
 // Work split: a workgroup owns 1024 pixels of one image (4 per thread, coalesced along x) and keeps their 8
-// mask-feature channels in registers (32 VGPRs); it then walks a strided subset of the image's instances.  The
-// 169 controller parameters of the current instance sit in LDS (double-buffered, one float per thread) and are
-// read with broadcast ds_read_b128 -- a weight row is fetched once and used for the 4 pixels.  Per (pixel,
-// instance): 152 FMAs ((8+2)*8 + 8*8 + 8), two ReLUs, one 4-byte store; nothing of size n_inst x (C+2) x H x W is
-// ever materialised.  fp32 FMAs on the VALU: the f32 MFMA runs at the same 157 TF vector rate
-// (MI355X_MICROARCH.md), so there is nothing to gain from the matrix core at this precision; the roofline that
-// binds is fp32 VALU issue (4.6 G FMA at 1800 instances x 100x167).
+// mask-feature channels in registers (as 16 channel pairs); it then walks a strided subset of the image's
+// instances.  The 169 controller parameters of the current instance sit in LDS (double-buffered, one float per
+// thread, transposed to [in][out]) and are read with broadcast ds_read_b128 -- a weight row (8 output channels of one
+// input) is fetched once and used for the 4 pixels.  Per (pixel, instance): 152 FMAs ((8+2)*8 + 8*8 + 8), two ReLUs,
+// one 4-byte store; nothing of size n_inst x (C+2) x H x W is ever materialised.  The two hidden layers run on
+// OUTPUT-CHANNEL PAIRS with v_pk_fma_f32 (72 packed + 8 scalar FMAs per pixel and instance instead of 152 scalar
+// ones; each output still sums its inputs in the reference order, so the result is bitwise the scalar kernel's).
+// fp32 on the VALU: the f32 MFMA runs at the same 157 TF vector rate (MI355X_MICROARCH.md); the roofline that binds
+// is fp32 VALU issue (4.6 G FMA at 1800 instances x 100x167).
 #include "../../include/dynmask_hip.h"
 
 #include "msda_common.hpp"
@@ -17,14 +19,20 @@ namespace dynmask {
 constexpr int kThreads = 256, kPx = 4;      // pixels per thread
 constexpr int kC = 8, kCh = 8;              // mask-feature channels, dynamic channels
 
-// LDS copy of one instance's parameters, rows padded to 12 floats so every row starts 16-byte aligned
+// LDS copy of one instance's parameters, input-major ([in][out]) so that a weight row holds the 8 output channels of
+// one input: the layers then run on OUTPUT-CHANNEL PAIRS with v_pk_fma_f32 (the weight pair comes straight out of the
+// ds_read_b128, the input is an op_sel broadcast) -- half the VALU instructions, same registers, and every output
+// still accumulates its inputs in the reference order (bitwise equal to the scalar form).
 struct __attribute__((aligned(16))) InstParams {
-  float w0[kCh][12];   // [out][in]: in 0,1 = relative x, y (or unused), 2.. = feature channels
-  float w1[kCh][8];
+  float w0[kC + 2][kCh];   // in 0,1 = relative x, y (unused without rel_coord), 2.. = feature channels
+  float w1[kCh][kCh];
   float w2[8];
   float b0[8], b1[8];
   float b2, ix, iy, pad;
 };
+
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 template <bool REL>
 __global__ void __launch_bounds__(kThreads, 2)
@@ -38,30 +46,58 @@ dynmask_fwd(const float* __restrict__ feats, const float* __restrict__ inst_xy, 
   const int p0 = blockIdx.x * (kThreads * kPx) + tid;
 
   // this thread's pixels: features in registers, pixel-centre coordinates in input pixels
-  float f[kPx][kC], lx[kPx], ly[kPx];
+  // kept as channel PAIRS: a v_pk_fma_f32 source is a 64-bit register tuple, the broadcast picks a half with op_sel
+  f32x2v f2[kPx][kC / 2], lxy[kPx];
 #pragma unroll
   for (int k = 0; k < kPx; ++k) {
     const int p = p0 + k * kThreads;
     const int pc = p < HW ? p : HW - 1;
 #pragma unroll
-    for (int c = 0; c < kC; ++c) f[k][c] = feats[(size_t)c * HW + pc];
+    for (int c = 0; c < kC; ++c) f2[k][c >> 1][c & 1] = feats[(size_t)c * HW + pc];
     const int py = pc / W, px = pc - py * W;
-    lx[k] = (float)(px * stride + stride / 2);
-    ly[k] = (float)(py * stride + stride / 2);
+    lxy[k] = f32x2v{(float)(px * stride + stride / 2), (float)(py * stride + stride / 2)};
   }
 
-  auto stage = [&](int inst, InstParams& dst) {   // one float per thread, reference layout -> padded rows
+  auto stage = [&](int inst, InstParams& dst) {   // one float per thread, reference layout ([out][in]) -> [in][out]
     if (tid < kNumParams) {
       const float v = params[(size_t)inst * kNumParams + tid];
       int t = tid;
-      if (t < kIn * kCh) { dst.w0[t / kIn][(REL ? 0 : 2) + t % kIn] = v; }
-      else if ((t -= kIn * kCh) < kCh * kCh) { dst.w1[t / kCh][t % kCh] = v; }
+      if (t < kIn * kCh) { dst.w0[(REL ? 0 : 2) + t % kIn][t / kIn] = v; }
+      else if ((t -= kIn * kCh) < kCh * kCh) { dst.w1[t % kCh][t / kCh] = v; }
       else if ((t -= kCh * kCh) < kCh) { dst.w2[t] = v; }
       else if ((t -= kCh) < kCh) { dst.b0[t] = v; }
       else if ((t -= kCh) < kCh) { dst.b1[t] = v; }
       else { dst.b2 = v; }
     }
     if (tid == kThreads - 1) { dst.ix = inst_xy[(size_t)inst * 2]; dst.iy = inst_xy[(size_t)inst * 2 + 1]; }
+  };
+  // one input row of a layer: acc[k][c] (channel pair c of pixel k) = w[c] * x[k] + (first ? bias[c] : acc[k][c]).
+  // The weights of row r + 1 are requested before row r is multiplied (Wrow ring of two); sched_barriers keep the
+  // scheduler from hoisting all 43 ds_read_b128 of an instance to the top (172 VGPRs -> spills).
+  struct Wrow { f32x4v a, b; };
+  auto fma_row = [](const Wrow& wr, const f32x2v (&xp)[kPx], int half, f32x2v (&acc)[kPx][4], const Wrow* bias, bool relu) {
+    const f32x2v w[4] = {wr.a.xy, wr.a.zw, wr.b.xy, wr.b.zw};
+    if (bias) {
+      const f32x2v b[4] = {bias->a.xy, bias->a.zw, bias->b.xy, bias->b.zw};
+#pragma unroll
+      for (int k = 0; k < kPx; ++k)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[k][c] = __builtin_elementwise_fma(w[c], (half ? xp[k].yy : xp[k].xx), b[c]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < kPx; ++k)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[k][c] = __builtin_elementwise_fma(w[c], (half ? xp[k].yy : xp[k].xx), acc[k][c]);
+    }
+    // the IR-level code sinking ignores sched_barrier: pin the row's results where they are computed (the ReLU of
+    // the last row sits before the pin, where the compiler still knows the value is an fma result: no canonicalize)
+#pragma unroll
+    for (int k = 0; k < kPx; ++k)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (relu) acc[k][c] = __builtin_elementwise_max(acc[k][c], f32x2v{0.f, 0.f});
+        asm volatile("" : "+v"(acc[k][c]));
+      }
   };
 
   int i = blockIdx.y;
@@ -71,38 +107,50 @@ dynmask_fwd(const float* __restrict__ feats, const float* __restrict__ inst_xy, 
     __syncthreads();                                   // sp[buf] is complete, sp[buf^1] is free
     if (i + (int)gridDim.y < inst_count) stage(inst_first + i + gridDim.y, sp[buf ^ 1]);
     const InstParams& P = sp[buf];
-    float h0[kPx][kCh];
+    constexpr int kFirst = REL ? 0 : 2;
+    const float* wbase = &P.w0[0][0];                  // rows 0..9 = w0, 10..17 = w1 (contiguous)
+    auto ld = [&](int r) { return Wrow{*reinterpret_cast<const f32x4v*>(wbase + 8 * r), *reinterpret_cast<const f32x4v*>(wbase + 8 * r + 4)}; };
+    const Wrow bias0 = Wrow{*reinterpret_cast<const f32x4v*>(&P.b0[0]), *reinterpret_cast<const f32x4v*>(&P.b0[4])};
+    Wrow wcur = ld(kFirst), wnxt;
+    f32x2v h0[kPx][4];
 #pragma unroll
-    for (int o = 0; o < kCh; ++o) {
-      const float4 wa = *reinterpret_cast<const float4*>(&P.w0[o][0]);
-      const float4 wb = *reinterpret_cast<const float4*>(&P.w0[o][4]);
-      const float2 wc = *reinterpret_cast<const float2*>(&P.w0[o][8]);
-      const float bo = P.b0[o];
+    for (int r = kFirst; r < kC + 2; ++r) {
+      wnxt = ld(r + 1);                                // r + 1 == 10 is the first row of w1
+      f32x2v xp[kPx];
+      if (r < 2) {
+        const f32x2v ixy = f32x2v{P.ix, P.iy};
 #pragma unroll
-      for (int k = 0; k < kPx; ++k) {
-        float a = bo;
-        if (REL) { a = fmaf(wa.x, P.ix - lx[k], a); a = fmaf(wa.y, P.iy - ly[k], a); }
-        a = fmaf(wa.z, f[k][0], a); a = fmaf(wa.w, f[k][1], a);
-        a = fmaf(wb.x, f[k][2], a); a = fmaf(wb.y, f[k][3], a); a = fmaf(wb.z, f[k][4], a); a = fmaf(wb.w, f[k][5], a);
-        a = fmaf(wc.x, f[k][6], a); a = fmaf(wc.y, f[k][7], a);
-        h0[k][o] = fmaxf(a, 0.f);
+        for (int k = 0; k < kPx; ++k) xp[k] = ixy - lxy[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < kPx; ++k) xp[k] = f2[k][(r - 2) >> 1];
       }
+      __builtin_amdgcn_sched_barrier(0);
+      fma_row(wcur, xp, r & 1, h0, r == kFirst ? &bias0 : nullptr, r == kC + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      wcur = wnxt;
     }
+    const Wrow bias1 = Wrow{*reinterpret_cast<const f32x4v*>(&P.b1[0]), *reinterpret_cast<const f32x4v*>(&P.b1[4])};
+    f32x2v h1[kPx][4];
+#pragma unroll
+    for (int c = 0; c < kCh; ++c) {
+      if (c + 1 < kCh) wnxt = ld(kC + 2 + c + 1);
+      f32x2v xp[kPx];
+#pragma unroll
+      for (int k = 0; k < kPx; ++k) xp[k] = h0[k][c >> 1];
+      __builtin_amdgcn_sched_barrier(0);
+      fma_row(wcur, xp, c & 1, h1, c == 0 ? &bias1 : nullptr, c == kCh - 1);
+      __builtin_amdgcn_sched_barrier(0);
+      wcur = wnxt;
+    }
+    const f32x4v w2a = *reinterpret_cast<const f32x4v*>(&P.w2[0]), w2b = *reinterpret_cast<const f32x4v*>(&P.w2[4]);
+    const float w2[8] = {w2a.x, w2a.y, w2a.z, w2a.w, w2b.x, w2b.y, w2b.z, w2b.w};
     float y[kPx];
 #pragma unroll
-    for (int k = 0; k < kPx; ++k) y[k] = P.b2;
+    for (int k = 0; k < kPx; ++k) {
+      y[k] = P.b2;
 #pragma unroll
-    for (int o = 0; o < kCh; ++o) {
-      const float4 wa = *reinterpret_cast<const float4*>(&P.w1[o][0]);
-      const float4 wb = *reinterpret_cast<const float4*>(&P.w1[o][4]);
-      const float bo = P.b1[o], w2o = P.w2[o];
-#pragma unroll
-      for (int k = 0; k < kPx; ++k) {
-        float a = bo;
-        a = fmaf(wa.x, h0[k][0], a); a = fmaf(wa.y, h0[k][1], a); a = fmaf(wa.z, h0[k][2], a); a = fmaf(wa.w, h0[k][3], a);
-        a = fmaf(wb.x, h0[k][4], a); a = fmaf(wb.y, h0[k][5], a); a = fmaf(wb.z, h0[k][6], a); a = fmaf(wb.w, h0[k][7], a);
-        y[k] = fmaf(w2o, fmaxf(a, 0.f), y[k]);
-      }
+      for (int o = 0; o < kCh; ++o) y[k] = fmaf(w2[o], h1[k][o >> 1][o & 1], y[k]);
     }
     float* o_ptr = out + (size_t)(inst_first + i) * HW;
 #pragma unroll
