@@ -13,6 +13,8 @@
 
 #include "msda_common.hpp"
 
+#include <cstdlib>
+
 namespace linear {
 
 typedef float f32x16 __attribute__((__vector_size__(64)));
@@ -328,8 +330,20 @@ static int linear_impl(const float* x, const float* x2, const void* packed, cons
   const int n_pad = linear::n_padded(out_features);
   const uint32_t* pk = static_cast<const uint32_t*>(packed);
   hipStream_t st = (hipStream_t)stream;
+  static const int forced_tj = std::getenv("LINEAR_TJ") ? std::atoi(std::getenv("LINEAR_TJ")) : 0;   // A/B hook: 1, 2, 4
+  // (the packed weights are padded to 128 columns only: a 256-column workgroup needs out_features % 256 == 0)
+  const bool wide_ok = out_features % 256 == 0 && mt * (out_features / 256) >= 512;
+  if (wide_ok && (forced_tj == 4 || (forced_tj == 0 && out_features == 256))) {
+    // 256 columns per workgroup: with out_features == 256 the activation tile is read, split and staged ONCE
+    // (-3.5 % at K = 256, -7 % at K = 1024; no gain for wider outputs, profiles/r01_linear_tiles.txt)
+    dim3 grid((unsigned)mt, (unsigned)((out_features + 255) / 256));
+    if (x2) hipLaunchKernelGGL((linear::linear_packed<4, BM, true, 1>), grid, dim3(linear::kThreads), 0, st, x, x2, pk, bias, row_mask, rows,
+                       in_features, out_features, n_pad, hm_rows, act, out);
+    else hipLaunchKernelGGL((linear::linear_packed<4, BM, false, 1>), grid, dim3(linear::kThreads), 0, st, x, x2, pk, bias, row_mask, rows,
+                       in_features, out_features, n_pad, hm_rows, act, out);
+  } else
   // 128 columns per workgroup unless that leaves CUs idle
-  if (out_features > 64 && mt * ((out_features + 127) / 128) >= 512) {
+  if (forced_tj == 2 || (forced_tj == 0 && out_features > 64 && mt * ((out_features + 127) / 128) >= 512)) {
     dim3 grid((unsigned)mt, (unsigned)((out_features + 127) / 128));
     if (x2) hipLaunchKernelGGL((linear::linear_packed<2, BM, true, 1>), grid, dim3(linear::kThreads), 0, st, x, x2, pk, bias, row_mask, rows,
                        in_features, out_features, n_pad, hm_rows, act, out);
