@@ -67,6 +67,20 @@ int linear_hip_packed_ln_f32(const float* x, const void* packed, const float* bi
                              const float* gamma, const float* beta, float eps, long long rows, int in_features,
                              int out_features, float* out, void* stream);
 
+/*
+ * The whole feed-forward block of the transformer layer in one kernel (d_model == 256, d_ffn % 128 == 0):
+ *     out[m, :] = f(residual[m, :] + bias2 + relu(x[m, :] W1^T + bias1) W2^T),   f = LayerNorm(.) * gamma + beta when
+ * layer_norm != 0, identity otherwise
+ * (`src2 = linear2(dropout(activation(linear1(src)))); src = norm2(src + dropout(src2))`,
+ * deformable_transformer_dino.py:354-357, dropout = identity at inference).  The [rows, d_ffn] hidden activations
+ * never leave the CU; products and accumulation order are those of linear_hip_packed_ex_f32 (ReLU) followed by
+ * linear_hip_packed_ln_f32, so the result is bitwise the two-call result.  packed1 / packed2: linear_hip_pack_weight_f32
+ * of W1 [d_ffn, d_model] and W2 [d_model, d_ffn]; bias1, bias2, residual, gamma, beta may be NULL.
+ */
+int linear_hip_packed_ffn_f32(const float* x, const void* packed1, const float* bias1, const void* packed2,
+                              const float* bias2, const float* residual, const float* gamma, const float* beta, float eps,
+                              int layer_norm, long long rows, int d_model, int d_ffn, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -189,3 +189,52 @@ def test_errors(dev):
     with pytest.raises(RuntimeError, match="contiguous"):
         ext.linear_packed_forward(torch.randn(64, 4, device=dev).t(), packed, 8)
     assert ext.linear_packed_forward(torch.randn(0, 64, device=dev), packed, 8).shape == (0, 8)
+
+
+@pytest.mark.parametrize("rows,d_ffn", [(1, 128), (63, 256), (64, 1024), (333, 1024), (1000, 384)])
+@pytest.mark.parametrize("layer_norm", [True, False])
+def test_fused_ffn_equals_two_kernel_path_and_oracle(rows, d_ffn, layer_norm, dev):
+    """linear_hip_packed_ffn_f32: bitwise the result of linear_packed_forward(relu) -> linear_packed_ln / forward, and
+    within 1e-4 of the float64 composition (deformable_transformer_dino.py:354-357)."""
+    from uninext_amd import ext
+    g = torch.Generator().manual_seed(rows * 7 + d_ffn)
+    x = torch.randn(rows, 256, generator=g).to(dev)
+    l1, l2 = torch.nn.Linear(256, d_ffn).to(dev), torch.nn.Linear(d_ffn, 256).to(dev)
+    ln = torch.nn.LayerNorm(256).to(dev)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5); ln.bias.uniform_(-0.5, 0.5)
+        p1, p2 = ext.linear_pack_weight(l1.weight), ext.linear_pack_weight(l2.weight)
+        hidden = ext.linear_packed_forward(x, p1, d_ffn, l1.bias, relu=True)
+        if layer_norm:
+            two = ext.linear_packed_ln(hidden, p2, l2.bias, x, ln.weight, ln.bias, ln.eps)
+        else:
+            two = ext.linear_packed_forward(hidden, p2, 256, l2.bias) + x
+        one = ext.ffn_packed(x, p1, l1.bias, p2, l2.bias, d_ffn, x, ln.weight, ln.bias, ln.eps, layer_norm=layer_norm)
+        assert one.shape == two.shape
+        if layer_norm and d_ffn % 256 != 0:
+            assert torch.equal(one, two)      # the 4-wave kernel repeats the two-kernel arithmetic exactly
+        else:   # 8 waves reduce the LayerNorm statistics in another order; without LayerNorm the residual is added
+            # inside the kernel: a few ulp either way
+            assert float((one - two).abs().max()) <= 4e-6 * float(two.abs().max())
+        xd = x.double()
+        want = xd + torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(xd, l1.weight.double(), l1.bias.double())),
+                                               l2.weight.double(), l2.bias.double())
+        if layer_norm:
+            want = torch.nn.functional.layer_norm(want, (256,), ln.weight.double(), ln.bias.double(), ln.eps)
+        assert float((one.double() - want).abs().max()) < 1e-4 * max(1.0, float(want.abs().max()))
+        # no biases, no residual
+        one = ext.ffn_packed(x, p1, None, p2, None, d_ffn, None, None, None, layer_norm=False)
+        want = torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(xd, l1.weight.double())), l2.weight.double())
+        assert float((one.double() - want).abs().max()) < 1e-4 * max(1.0, float(want.abs().max()))
+
+
+def test_fused_ffn_rejects_unsupported(dev):
+    from uninext_amd import ext
+    x = torch.randn(8, 256, device=dev)
+    w1, w2 = torch.randn(192, 256, device=dev), torch.randn(256, 192, device=dev)
+    assert not ext.ffn_packed_supported(x, w1, w2, (256,))
+    p1, p2 = ext.linear_pack_weight(w1), ext.linear_pack_weight(w2)
+    with pytest.raises(RuntimeError):
+        ext.ffn_packed(x, p1, None, p2, None, 192)
+    with pytest.raises(RuntimeError):
+        ext.ffn_packed(x, p1, None, p2, None, 256)   # packed sizes do not match d_ffn

@@ -19,7 +19,8 @@ DYNMASK_EXPORTS = ("dynmask_hip_forward_f32", "aligned_bilinear_hip_f32")   # in
 PATCH_EMBED_EXPORTS = ("patch_embed_hip_f32", "patch_embed_hip_packed_weight_bytes", "patch_embed_hip_pack_weight_f32",
                        "patch_embed_hip_packed_f32")                           # include/patch_embed_hip.h
 LINEAR_EXPORTS = ("linear_hip_packed_weight_bytes", "linear_hip_pack_weight_f32", "linear_hip_packed_f32",
-                  "linear_hip_packed_hm_f32", "linear_hip_packed_ex_f32", "linear_hip_packed_ln_f32")   # include/linear_hip.h
+                  "linear_hip_packed_hm_f32", "linear_hip_packed_ex_f32", "linear_hip_packed_ln_f32",
+                  "linear_hip_packed_ffn_f32")   # include/linear_hip.h
 LAYERNORM_EXPORTS = ("add_layernorm_hip_f32",)                                 # include/layernorm_hip.h
 LSAP_EXPORTS = ("lsap_hip_workspace_bytes", "lsap_hip_f32", "lsap_hip_batch_f32")   # include/lsap_hip.h
 LSAP_MAX_BATCH = 32
@@ -58,6 +59,8 @@ def load():
     lib.linear_hip_packed_ex_f32.restype = i
     lib.linear_hip_packed_ln_f32.argtypes = [p, p, p, p, p, p, ctypes.c_float, ctypes.c_longlong, i, i, p, p]
     lib.linear_hip_packed_ln_f32.restype = i
+    lib.linear_hip_packed_ffn_f32.argtypes = [p, p, p, p, p, p, p, p, ctypes.c_float, i, ctypes.c_longlong, i, i, p, p]
+    lib.linear_hip_packed_ffn_f32.restype = i
     lib.add_layernorm_hip_f32.argtypes = [p, p, p, p, ctypes.c_float, ctypes.c_longlong, i, p, p]
     lib.add_layernorm_hip_f32.restype = i
     lib.lsap_hip_workspace_bytes.argtypes, lib.lsap_hip_workspace_bytes.restype = [i, i], ctypes.c_size_t

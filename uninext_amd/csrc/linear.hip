@@ -52,6 +52,85 @@ __device__ __forceinline__ float msda_dpp(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 
+// out = LayerNorm(acc + bias + residual) * gamma + beta for a workgroup that holds whole rows: NW waves x (2 row tiles x WJ
+// column tiles), wave `wv` owns columns wn .. wn + 32 WJ - 1 of the N = 32 WJ NW columns, all 64 rows.  Two-pass
+// statistics like add_layernorm: row sums are reduced over the 32 lanes of a half-wave with DPP + one xor-16 exchange,
+// then over the waves through `red` (>= 64 (NW + 1) floats of LDS that nobody else touches any more).
+template <int WJ, int NW = 4>
+__device__ __forceinline__ void layernorm_epilogue(const f32x16 (&acc)[2][WJ], const float* __restrict__ bias,
+                                                   const LnArgs& ln, float* red, long long m0, long long M, int N, int wn,
+                                                   int tid, float* __restrict__ out) {
+  constexpr int TI = 2;
+  const int lane = tid & 63, wv = tid >> 6, r32 = lane & 31, half = lane >> 5;
+  auto sum32 = [](float v) {
+    v += msda_dpp<0xB1>(v); v += msda_dpp<0x4E>(v); v += msda_dpp<0x141>(v); v += msda_dpp<0x140>(v);
+    return v + __shfl_xor(v, 16, 64);
+  };
+  float val[TI][WJ][16];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int jn = 0; jn < WJ; ++jn) {
+      const int n = wn + jn * 32 + r32;
+      const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        long long m = m0 + i * 32 + 8 * (v / 4) + 4 * half + (v % 4);
+        m = m < M ? m : M - 1;
+        val[i][jn][v] = acc[i][jn][v] + bv + (ln.residual ? ln.residual[m * N + n] : 0.f);
+      }
+    }
+  float stat[TI][16];
+  auto reduce_rows = [&](bool centred, const float (&mean)[TI][16]) {
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        float p = 0.f;
+#pragma unroll
+        for (int jn = 0; jn < WJ; ++jn) {
+          const float t = centred ? val[i][jn][v] - mean[i][v] : val[i][jn][v];
+          p += centred ? t * t : t;
+        }
+        p = sum32(p);
+        if (r32 == 0) red[wv * 64 + i * 32 + 8 * (v / 4) + 4 * half + (v % 4)] = p;
+      }
+    __syncthreads();
+    if (tid < 64) {
+      float t = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
+      if constexpr (NW == 8) t += (red[256 + tid] + red[320 + tid]) + (red[384 + tid] + red[448 + tid]);
+      red[64 * NW + tid] = t;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) stat[i][v] = red[64 * NW + i * 32 + 8 * (v / 4) + 4 * half + (v % 4)];
+    __syncthreads();   // `red` is rewritten by the next pass
+  };
+  float mean[TI][16];
+  reduce_rows(false, mean);
+  const float inv_n = 1.0f / (float)N;
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) mean[i][v] = stat[i][v] * inv_n;
+  reduce_rows(true, mean);
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int jn = 0; jn < WJ; ++jn) {
+      const int n = wn + jn * 32 + r32;
+      const float gmm = ln.gamma ? ln.gamma[n] : 1.f, bt = ln.beta ? ln.beta[n] : 0.f;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const long long m = m0 + i * 32 + 8 * (v / 4) + 4 * half + (v % 4);
+        const float rstd = rsqrtf(stat[i][v] * inv_n + ln.eps);
+        if (m < M) out[m * N + n] = (val[i][jn][v] - mean[i][v]) * rstd * gmm + bt;
+      }
+    }
+}
+
 template <int TJ, int BM, bool ADD, int WM, bool LN = false>   // ADD: the input is x + x2
 __global__ void __launch_bounds__(kThreads, 2)
 linear_packed(const float* __restrict__ x, const float* __restrict__ x2, const uint32_t* __restrict__ packed,
@@ -166,73 +245,9 @@ linear_packed(const float* __restrict__ x, const float* __restrict__ x2, const u
 
   if constexpr (LN) {
     // ---- out = LayerNorm(acc + bias + residual) * gamma + beta: the workgroup holds whole rows (N == 64 TJ columns,
-    // a quarter per wave).  Two-pass statistics like add_layernorm: row sums are reduced over the 32 lanes of a
-    // half-wave with DPP + one xor-16 exchange, then over the four waves through LDS (the operand tile is dead by now).
+    // a quarter per wave); the operand tile is dead by now and lends its LDS to the row statistics
     static_assert(WM == 1 && BM == 64, "LayerNorm epilogue: every wave spans the 64 rows");
-    float* red = reinterpret_cast<float*>(&As[0][0][0][0][0]);   // [4 waves][64 rows] partial sums, then [64] totals at +256
-    auto sum32 = [](float v) {
-      v += msda_dpp<0xB1>(v); v += msda_dpp<0x4E>(v); v += msda_dpp<0x141>(v); v += msda_dpp<0x140>(v);
-      return v + __shfl_xor(v, 16, 64);
-    };
-    float val[TI][WJ][16];
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-      for (int jn = 0; jn < WJ; ++jn) {
-        const int n = wn + jn * 32 + r32;
-        const float bv = bias ? bias[n] : 0.f;
-#pragma unroll
-        for (int v = 0; v < 16; ++v) {
-          long long m = m0 + wm + i * 32 + 8 * (v / 4) + 4 * half + (v % 4);
-          m = m < M ? m : M - 1;
-          val[i][jn][v] = acc[i][jn][v] + bv + (ln.residual ? ln.residual[m * N + n] : 0.f);
-        }
-      }
-    float stat[TI][16];
-    auto reduce_rows = [&](bool centred, const float (&mean)[TI][16]) {
-#pragma unroll
-      for (int i = 0; i < TI; ++i)
-#pragma unroll
-        for (int v = 0; v < 16; ++v) {
-          float p = 0.f;
-#pragma unroll
-          for (int jn = 0; jn < WJ; ++jn) {
-            const float t = centred ? val[i][jn][v] - mean[i][v] : val[i][jn][v];
-            p += centred ? t * t : t;
-          }
-          p = sum32(p);
-          if (r32 == 0) red[wv * 64 + i * 32 + 8 * (v / 4) + 4 * half + (v % 4)] = p;
-        }
-      __syncthreads();
-      if (tid < 64) red[256 + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < TI; ++i)
-#pragma unroll
-        for (int v = 0; v < 16; ++v) stat[i][v] = red[256 + i * 32 + 8 * (v / 4) + 4 * half + (v % 4)];
-      __syncthreads();   // `red` is rewritten by the next pass
-    };
-    float mean[TI][16];
-    reduce_rows(false, mean);
-    const float inv_n = 1.0f / (float)N;
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-      for (int v = 0; v < 16; ++v) mean[i][v] = stat[i][v] * inv_n;
-    reduce_rows(true, mean);
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-      for (int jn = 0; jn < WJ; ++jn) {
-        const int n = wn + jn * 32 + r32;
-        const float gmm = ln.gamma ? ln.gamma[n] : 1.f, bt = ln.beta ? ln.beta[n] : 0.f;
-#pragma unroll
-        for (int v = 0; v < 16; ++v) {
-          const long long m = m0 + wm + i * 32 + 8 * (v / 4) + 4 * half + (v % 4);
-          const float rstd = rsqrtf(stat[i][v] * inv_n + ln.eps);
-          if (m < M) out[m * N + n] = (val[i][jn][v] - mean[i][v]) * rstd * gmm + bt;
-        }
-      }
+    layernorm_epilogue<WJ>(acc, bias, ln, reinterpret_cast<float*>(&As[0][0][0][0][0]), m0, M, N, wn, tid, out);
     return;
   }
   // epilogue: accumulator register v of lane l is (row 8 (v / 4) + 4 (l / 32) + v % 4, column l % 32)
@@ -270,6 +285,219 @@ linear_packed(const float* __restrict__ x, const float* __restrict__ x2, const u
         }
       }
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused feed-forward block: out = [LayerNorm](residual + b2 + relu(x W1^T + b1) W2^T) for d_model = 256.
+// The two Linear kernels above spend most of their time moving the [rows, d_ffn] hidden tensor (182 MB written and read
+// back at the R50 shapes); here a workgroup keeps its 64 rows on the CU: the split x tile (all 256 k) stays in LDS,
+// the hidden activations are produced 128 columns at a time (phase 1, TRANSPOSED accumulator tiles -- weights as the
+// A operand -- so that a lane holds 4 consecutive hidden columns of one row and writes them as one 8-byte LDS store,
+// split into bf16 hi / lo on the way), and are consumed at once as the K operand of the second product (phase 2),
+// whose 64 x 256 fp32 accumulators live in registers for the whole kernel.  Both weight matrices stream from L2 through
+// two register rings that stay primed across the phases; one barrier per 128 hidden columns (double-buffered hidden
+// tile).  Products, operand order and accumulation order are those of linear_packed, so the result equals the
+// two-kernel path bit for bit.  133 KB of LDS: one workgroup (4 waves) per CU.
+constexpr int kFfnD = 256, kFfnBM = 64;
+constexpr int kFfnXsWords = 2 * (kFfnD / kChunk) * (kFfnBM + 1) * 8;
+constexpr int kFfnHsWords = 2 * 2 * (128 / kChunk) * (kFfnBM + 1) * 8;   // two 128-column tiles, or one of 256 columns
+constexpr int kFfnLdsBytes = (kFfnXsWords + kFfnHsWords) * 4;
+
+// NW waves (4 or 8): a hidden chunk is 32 NW columns (one 32-column tile per wave in phase 1), phase 2 gives every
+// wave 256 / NW output columns.  NW = 8 puts TWO waves on each SIMD -- while one converts its hidden tile on the VALU
+// or waits for a weight fragment the other keeps the matrix pipe busy -- at the price of a single hidden buffer (two
+// barriers per chunk) and needs d_ffn % 256 == 0.
+template <bool LN, int NW>
+__global__ void __launch_bounds__(64 * NW, 1)
+ffn_packed(const float* __restrict__ x, const uint32_t* __restrict__ packed1, const float* __restrict__ bias1,
+           const uint32_t* __restrict__ packed2, const float* __restrict__ bias2, long long M, int F, int f_pad,
+           float* __restrict__ out, LnArgs ln) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t ffn_smem[];
+  constexpr int kFfnHC = 32 * NW, WJ2 = 8 / NW, NBUF = NW == 4 ? 2 : 1;
+  constexpr int KC1 = kFfnD / kChunk, KC2 = kFfnHC / kChunk, BM = kFfnBM;
+  typedef uint32_t (*XsT)[KC1][BM + 1][8];        // [hi / lo][k chunk][row][16 bf16]
+  typedef uint32_t (*HsT)[2][KC2][BM + 1][8];     // [buffer][hi / lo][k chunk][row][16 bf16]
+  XsT Xs = reinterpret_cast<XsT>(ffn_smem);
+  HsT Hs = reinterpret_cast<HsT>(ffn_smem + kFfnXsWords);
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r32 = lane & 31, half = lane >> 5;
+  const long long m0 = (long long)blockIdx.x * BM;
+
+  // weight fragment streams: g1 = (hidden chunk, k chunk) of W1 in execution order, g2 = k chunk of W2
+  struct W1F { u32x4v hi, lo; };
+  struct W2F { u32x4v hi[WJ2], lo[WJ2]; };
+  const int n1 = (F / kFfnHC) * KC1, n2 = F / kChunk;
+  const long long cs1 = (long long)2 * f_pad * 8, ps1 = (long long)f_pad * 8;
+  const long long cs2 = (long long)2 * kFfnD * 8, ps2 = (long long)kFfnD * 8;
+  const uint32_t* w1_lane = packed1 + (long long)(wv * 32 + r32) * 8 + half * 4;
+  const uint32_t* w2_lane = packed2 + (long long)(wv * 32 * WJ2 + r32) * 8 + half * 4;
+  auto load_w1 = [&](int g, W1F& f) {
+    g = g < n1 ? g : n1 - 1;
+    const uint32_t* p = w1_lane + (long long)(g % KC1) * cs1 + (long long)(g / KC1) * (kFfnHC * 8);
+    f.hi = *reinterpret_cast<const u32x4v*>(p);
+    f.lo = *reinterpret_cast<const u32x4v*>(p + ps1);
+  };
+  auto load_w2 = [&](int g, W2F& f) {
+    g = g < n2 ? g : n2 - 1;
+    const uint32_t* p = w2_lane + (long long)g * cs2;
+#pragma unroll
+    for (int jn = 0; jn < WJ2; ++jn) {
+      f.hi[jn] = *reinterpret_cast<const u32x4v*>(p + jn * 32 * 8);
+      f.lo[jn] = *reinterpret_cast<const u32x4v*>(p + ps2 + jn * 32 * 8);
+    }
+  };
+  // one wave per SIMD: nothing but the rings hides the L2 latency of the weight fragments (R - 1 chunks ahead)
+  constexpr int R1 = 8, R2 = 8;
+  static_assert(KC1 % R1 == 0 && KC2 % R2 == 0, "ring slots are compile-time constants");
+  W1F ring1[R1];
+  W2F ring2[R2];
+#pragma unroll
+  for (int r = 0; r < R1 - 1; ++r) load_w1(r, ring1[r]);
+#pragma unroll
+  for (int r = 0; r < R2 - 1; ++r) load_w2(r, ring2[r]);
+
+  // ---- phase 0: the 64 x 256 tile of x, split, into LDS (a step = 64 k = 16 pieces of 16 bytes per row) --------
+  {
+    const int s_piece = tid & 15, s_row0 = tid >> 4;
+    const int cc = s_piece >> 2, w2 = (s_piece & 3) * 2;
+    constexpr int RS = 4 * NW, NR = BM / RS;            // rows per pass, passes
+    f32x4 xa[4][NR];
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        long long mr = m0 + s_row0 + RS * r;
+        mr = mr < M ? mr : M - 1;
+        xa[st][r] = *reinterpret_cast<const f32x4*>(x + mr * kFfnD + st * kStepK + s_piece * 4);
+      }
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        uint32_t hi[2], lo[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const float fa = xa[st][r][2 * p], fb = xa[st][r][2 * p + 1];
+          const uint32_t ah = __float_as_uint(fa) & 0xffff0000u, bh = __float_as_uint(fb) & 0xffff0000u;
+          const uint32_t al = __float_as_uint(fa - __uint_as_float(ah)), bl = __float_as_uint(fb - __uint_as_float(bh));
+          hi[p] = (ah >> 16) | bh;
+          lo[p] = ((al + 0x8000u) >> 16) | ((bl + 0x8000u) & 0xffff0000u);   // lo rounded to nearest
+        }
+        *reinterpret_cast<uint2*>(&Xs[0][st * 4 + cc][s_row0 + RS * r][w2]) = make_uint2(hi[0], hi[1]);
+        *reinterpret_cast<uint2*>(&Xs[1][st * 4 + cc][s_row0 + RS * r][w2]) = make_uint2(lo[0], lo[1]);
+      }
+  }
+  __syncthreads();
+
+  f32x16 acc2[2][WJ2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jn = 0; jn < WJ2; ++jn)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc2[i][jn][v] = 0.f;
+
+  const int nhc = F / kFfnHC;
+  // ---- phase 1: hT[hidden column, row] for this wave's 32 hidden columns x 64 rows of hidden chunk hc ------------
+  auto phase1 = [&](int hc, f32x16 (&acc1)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc1[i][v] = 0.f;
+    const int g1 = hc * KC1;
+#pragma unroll
+    for (int kc = 0; kc < KC1; ++kc) {
+      load_w1(g1 + kc + R1 - 1, ring1[(kc + R1 - 1) % R1]);
+      const W1F& wf = ring1[kc % R1];
+      const bf16x8 wh = __builtin_bit_cast(bf16x8, wf.hi), wl = __builtin_bit_cast(bf16x8, wf.lo);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(&Xs[0][kc][i * 32 + r32][half * 4]));
+        const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(&Xs[1][kc][i * 32 + r32][half * 4]));
+        acc1[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, ah, acc1[i], 0, 0, 0);   // weights as A: transposed tile
+        acc1[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, al, acc1[i], 0, 0, 0);
+        acc1[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ah, acc1[i], 0, 0, 0);
+      }
+    }
+  };
+  // bias + ReLU + split -> Hs[hc & 1]; register v of lane l is (hidden column 8 (v / 4) + 4 (l / 32) + v % 4, row l % 32)
+  auto hidden_to_lds = [&](int hc, const f32x16 (&acc1)[2]) {
+    const int hb = hc & (NBUF - 1);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int col = hc * kFfnHC + wv * 32 + 8 * g + 4 * half;
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (bias1) bv = *reinterpret_cast<const f32x4*>(bias1 + col);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        uint32_t hi[2], lo[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const float fa = fmaxf(acc1[i][4 * g + 2 * p] + bv[2 * p], 0.f), fb = fmaxf(acc1[i][4 * g + 2 * p + 1] + bv[2 * p + 1], 0.f);
+          const uint32_t ah = __float_as_uint(fa) & 0xffff0000u, bh = __float_as_uint(fb) & 0xffff0000u;
+          const uint32_t al = __float_as_uint(fa - __uint_as_float(ah)), bl = __float_as_uint(fb - __uint_as_float(bh));
+          hi[p] = (ah >> 16) | bh;
+          lo[p] = ((al + 0x8000u) >> 16) | ((bl + 0x8000u) & 0xffff0000u);
+        }
+        const int kc = wv * 2 + (g >> 1), word = 4 * (g & 1) + 2 * half;
+        *reinterpret_cast<uint2*>(&Hs[hb][0][kc][i * 32 + r32][word]) = make_uint2(hi[0], hi[1]);
+        *reinterpret_cast<uint2*>(&Hs[hb][1][kc][i * 32 + r32][word]) = make_uint2(lo[0], lo[1]);
+      }
+    }
+  };
+  // ---- phase 2: out[row, column] += h[row, 128 hidden of chunk hc] W2[column, the same 128 hidden] ---------------
+  auto phase2 = [&](int hc) {
+    const int hb = hc & (NBUF - 1), g2 = hc * KC2;
+#pragma unroll
+    for (int kc = 0; kc < KC2; ++kc) {
+      load_w2(g2 + kc + R2 - 1, ring2[(kc + R2 - 1) % R2]);
+      const W2F& wf = ring2[kc % R2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(&Hs[hb][0][kc][i * 32 + r32][half * 4]));
+        const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(&Hs[hb][1][kc][i * 32 + r32][half * 4]));
+#pragma unroll
+        for (int jn = 0; jn < WJ2; ++jn) {
+          const bf16x8 wh = __builtin_bit_cast(bf16x8, wf.hi[jn]), wl = __builtin_bit_cast(bf16x8, wf.lo[jn]);
+          acc2[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl, acc2[i][jn], 0, 0, 0);
+          acc2[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh, acc2[i][jn], 0, 0, 0);
+          acc2[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc2[i][jn], 0, 0, 0);
+        }
+      }
+    }
+  };
+  // NW = 4: one barrier per chunk -- it publishes Hs[hc & 1]; the other buffer is free again by then (every wave has
+  // left the phase 2 that read it).  NW = 8: a single buffer, so a second barrier retires its readers.  Issuing
+  // phase2(hc - 1) between phase1(hc) and its epilogue instead (to give the matrix pipe work while the VALU converts)
+  // measured 17 % slower: the in-order wave only reaches the VALU code later.
+  for (int hc = 0; hc < nhc; ++hc) {
+    f32x16 acc1[2];
+    phase1(hc, acc1);
+    if (NBUF == 1 && hc > 0) __syncthreads();
+    hidden_to_lds(hc, acc1);
+    __syncthreads();
+    phase2(hc);
+  }
+
+  const int wn = wv * 32 * WJ2;
+  if constexpr (LN) {
+    // Xs is dead since the last barrier (phase 2 only reads the hidden tile): it lends its LDS to the row statistics
+    layernorm_epilogue<WJ2, NW>(acc2, bias2, ln, reinterpret_cast<float*>(ffn_smem), m0, M, kFfnD, wn, tid, out);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jn = 0; jn < WJ2; ++jn) {
+        const int n = wn + jn * 32 + r32;
+        const float bv = bias2 ? bias2[n] : 0.f;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const long long m = m0 + i * 32 + 8 * (v / 4) + 4 * half + (v % 4);
+          if (m < M) out[m * kFfnD + n] = acc2[i][jn][v] + bv + (ln.residual ? ln.residual[m * kFfnD + n] : 0.f);
+        }
+      }
   }
 }
 
@@ -396,6 +624,38 @@ int linear_hip_packed_ex_f32(const float* x, const float* x_add, const void* pac
                              const uint8_t* row_mask, long long rows, int in_features, int out_features, int activation,
                              float* out, void* stream) {
   return linear_impl(x, x_add, packed, bias, row_mask, rows, in_features, out_features, 0, activation, out, stream);
+}
+
+int linear_hip_packed_ffn_f32(const float* x, const void* packed1, const float* bias1, const void* packed2,
+                              const float* bias2, const float* residual, const float* gamma, const float* beta, float eps,
+                              int layer_norm, long long rows, int d_model, int d_ffn, float* out, void* stream) {
+  if (rows < 0 || d_model <= 0 || d_ffn <= 0) return dynmask_set_error(LINEAR_ERR_BAD_DIMS, "ffn: bad dimensions");
+  if (d_model != linear::kFfnD || d_ffn % 128 != 0)
+    return dynmask_set_error(LINEAR_ERR_UNSUPPORTED, "ffn: d_model must be 256 and d_ffn a multiple of 128");
+  if (rows == 0) return 0;
+  const long long mt = (rows + linear::kFfnBM - 1) / linear::kFfnBM;
+  if (mt >= (1ll << 31)) return dynmask_set_error(LINEAR_ERR_BAD_DIMS, "ffn: problem too large");
+  if (!x || !packed1 || !packed2 || !out) return dynmask_set_error(LINEAR_ERR_NULL_POINTER, "ffn: null pointer argument");
+  const linear::LnArgs ln{residual, gamma, beta, eps};
+  const uint32_t* p1 = static_cast<const uint32_t*>(packed1);
+  const uint32_t* p2 = static_cast<const uint32_t*>(packed2);
+  const int f_pad = linear::n_padded(d_ffn);
+  static const int forced_nw = std::getenv("LINEAR_FFN_WAVES") ? std::atoi(std::getenv("LINEAR_FFN_WAVES")) : 0;   // A/B hook
+  const bool eight = d_ffn % 256 == 0 && forced_nw != 4;
+  static std::atomic<uint64_t> opted_in[4];
+  auto launch = [&](auto kernel, int nw, std::atomic<uint64_t>& done) -> int {
+    if (int rc = msda::ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), linear::kFfnLdsBytes, done))
+      return dynmask_set_error(rc, "ffn: dynamic LDS opt-in failed");
+    hipLaunchKernelGGL(kernel, dim3((unsigned)mt), dim3(64 * nw), linear::kFfnLdsBytes, (hipStream_t)stream, x, p1, bias1,
+                       p2, bias2, rows, d_ffn, f_pad, out, ln);
+    return 0;
+  };
+  int rc;
+  if (layer_norm) rc = eight ? launch(linear::ffn_packed<true, 8>, 8, opted_in[0]) : launch(linear::ffn_packed<true, 4>, 4, opted_in[1]);
+  else rc = eight ? launch(linear::ffn_packed<false, 8>, 8, opted_in[2]) : launch(linear::ffn_packed<false, 4>, 4, opted_in[3]);
+  if (rc) return rc;
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : dynmask_set_error((int)e, hipGetErrorString(e));
 }
 
 }  // extern "C"

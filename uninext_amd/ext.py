@@ -583,3 +583,47 @@ def linear_packed_ln(x, packed, bias, residual, ln_weight, ln_bias, eps):
     if rc != 0:
         _raise(rc)
     return out
+
+
+def ffn_packed_supported(x, weight1, weight2, norm_shape=None):
+    """True when linear_hip_packed_ffn_f32 covers `linear2(relu(linear1(x)))` (+ residual, + LayerNorm): fp32 GPU
+    tensors, d_model == 256, d_ffn a multiple of 128."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == 256
+            and weight1.dtype == torch.float32 and weight2.dtype == torch.float32
+            and weight1.dim() == 2 and weight2.dim() == 2 and weight1.shape[1] == 256 and weight2.shape[0] == 256
+            and weight1.shape[0] == weight2.shape[1] and weight1.shape[0] % 128 == 0
+            and (norm_shape is None or tuple(norm_shape) == (256,)))
+
+
+def ffn_packed(x, packed1, bias1, packed2, bias2, d_ffn, residual=None, ln_weight=None, ln_bias=None, eps=1e-5,
+               layer_norm=True):
+    """[LayerNorm](residual + F.linear(relu(F.linear(x, W1, bias1)), W2, bias2)) in one kernel: the hidden activations
+    stay on the CU (include/linear_hip.h).  packed1 / packed2 = linear_pack_weight(W1 [d_ffn, 256]) / (W2 [256, d_ffn]).
+    Bitwise equal to linear_packed_forward(..., relu=True) followed by linear_packed_ln / linear_packed_forward."""
+    lib = _lib.load()
+    _check("x", x, x.device)
+    _check("packed1", packed1, x.device)
+    _check("packed2", packed2, x.device)
+    k, n = x.shape[-1], 256
+    rows = x.numel() // k if k else 0
+    for name, t, shape in (("bias1", bias1, (d_ffn,)), ("bias2", bias2, (n,)), ("ln_weight", ln_weight, (n,)),
+                           ("ln_bias", ln_bias, (n,)), ("residual", residual, tuple(x.shape))):
+        if t is not None:
+            _check(name, t, x.device)
+            if t.dtype != torch.float32 or tuple(t.shape) != tuple(shape):
+                raise RuntimeError("ffn_packed: %s must be float32 %s" % (name, tuple(shape)))
+    if (x.dtype != torch.float32 or k != n or d_ffn <= 0 or d_ffn % 128 != 0 or packed1.dtype != torch.uint8
+            or packed2.dtype != torch.uint8 or packed1.numel() != lib.linear_hip_packed_weight_bytes(d_ffn, k)
+            or packed2.numel() != lib.linear_hip_packed_weight_bytes(n, d_ffn)):
+        raise RuntimeError("ffn_packed: expected float32 x [..., 256] and the packed copies of [%d, 256] and [256, %d] "
+                           "weights (d_ffn a multiple of 128)" % (d_ffn, d_ffn))
+    out = torch.empty_like(x)
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    with torch.cuda.device(x.device):
+        rc = lib.linear_hip_packed_ffn_f32(x.data_ptr(), packed1.data_ptr(), ptr(bias1), packed2.data_ptr(), ptr(bias2),
+                                           ptr(residual), ptr(ln_weight), ptr(ln_bias), float(eps), 1 if layer_norm else 0,
+                                           rows, k, d_ffn, out.data_ptr(),
+                                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc != 0:
+        _raise(rc)
+    return out

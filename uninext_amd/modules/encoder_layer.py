@@ -8,7 +8,8 @@ around `MSDeformAttn`.  At inference on the GPU (dropout is the identity):
   * `with_pos_embed(src, pos)` is folded into the operand load of the sampling_offsets / attention_weights projections;
   * `src + dropout(src2)` followed by `normN` runs in the epilogue of the Linear that produced src2 (output_proj,
     linear2: `linear_hip_packed_ln_f32`; a stand-alone add + LayerNorm kernel, include/layernorm_hip.h, covers other widths);
-  * `linear1` + ReLU and `linear2` run on include/linear_hip.h (split-bf16 MFMA, packed weights, ReLU in the epilogue).
+  * `linear1` + ReLU + `linear2` + residual + `norm2` run as ONE kernel (`linear_hip_packed_ffn_f32`: the hidden
+    activations never leave the CU); `fuse_ffn = False` or other activations / widths take the two Linear kernels.
 """
 import torch
 import torch.nn.functional as F
@@ -29,6 +30,8 @@ def _get_activation_fn(activation):
 
 
 class DeformableTransformerEncoderLayer(nn.Module):
+    fuse_ffn = True   # inference: linear1 + ReLU + linear2 + residual + norm2 as one kernel (include/linear_hip.h)
+
     def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4, n_heads=8, n_points=4):
         super().__init__()
         self.self_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
@@ -74,6 +77,10 @@ class DeformableTransformerEncoderLayer(nn.Module):
         attn = self.self_attn
         src = attn(src, reference_points, src, spatial_shapes, level_start_index, padding_mask, query_pos=pos,
                    residual_norm=(src, self.norm1))                       # norm1(src + attention) in output_proj's epilogue
+        if self._relu and self.fuse_ffn:
+            out = attn._ffn_norm(self.linear1, self.linear2, src, self.norm2)   # the whole FFN block in one kernel
+            if out is not None:
+                return out
         hidden = attn._project(self.linear1, src, relu=self._relu)
         if not self._relu:
             hidden = self.activation(hidden)

@@ -115,6 +115,16 @@ class MSDeformAttn(nn.Module):
             return MSDA.linear_packed_ln(x, self._packed(lin), lin.bias, residual, norm.weight, norm.bias, norm.eps)
         return norm(residual + self._project(lin, x))
 
+    def _ffn_norm(self, lin1, lin2, x, norm):
+        """`norm(x + lin2(relu(lin1(x))))` in one kernel when include/linear_hip.h covers the shapes (d_model 256,
+        d_ffn % 128 == 0, inference), else None."""
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or lin1.weight.requires_grad or lin2.weight.requires_grad)
+        if (self.fast_linear and not needs_grad and x.is_contiguous() and norm.elementwise_affine
+                and MSDA.ffn_packed_supported(x, lin1.weight, lin2.weight, norm.normalized_shape)):
+            return MSDA.ffn_packed(x, self._packed(lin1), lin1.bias, self._packed(lin2), lin2.bias, lin1.weight.shape[0],
+                                   x, norm.weight, norm.bias, norm.eps)
+        return None
+
     def _project(self, lin, x, row_mask=None, head_major_rows=0, x_add=None, relu=False):
         """`lin(x)` (then zero the rows where row_mask is True).  Inference on the GPU: include/linear_hip.h from a
         packed copy of the weight cached on the Linear and rebuilt when the parameter changes; head_major_rows = S
