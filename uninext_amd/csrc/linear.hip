@@ -300,8 +300,14 @@ linear_packed(const float* __restrict__ x, const float* __restrict__ x2, const u
 // tile).  Products, operand order and accumulation order are those of linear_packed, so the result equals the
 // two-kernel path bit for bit.  133 KB of LDS: one workgroup (4 waves) per CU.
 constexpr int kFfnD = 256, kFfnBM = 64;
-constexpr int kFfnXsWords = 2 * (kFfnD / kChunk) * (kFfnBM + 1) * 8;
-constexpr int kFfnHsWords = 2 * 2 * (128 / kChunk) * (kFfnBM + 1) * 8;   // two 128-column tiles, or one of 256 columns
+// LDS operand tiles are [k chunk][k half (0-7 / 8-15)][row][8 bf16]: with a 16-byte row pitch each 16-lane group that
+// the hardware serves per ds_read_b128 pass ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, +32) covers the 64 banks exactly
+// once; the [row][16 bf16] layout (32-byte pitch) has 2-way conflicts on every operand read (measured: conflict cycles =
+// 65 % of the LDS instruction cycles, profiles/r01_ffn_pmc_before_lds_fix.txt).  8 pad words per plane spread the
+// staging stores of the different (chunk, half) over the banks.
+constexpr int kPlane = kFfnBM * 4 + 8;                                   // words per [row][8 bf16] plane
+constexpr int kFfnXsWords = 2 * (kFfnD / kChunk) * 2 * kPlane;
+constexpr int kFfnHsWords = 2 * 2 * (128 / kChunk) * 2 * kPlane;          // two 128-column tiles, or one of 256 columns
 constexpr int kFfnLdsBytes = (kFfnXsWords + kFfnHsWords) * 4;
 
 // NW waves (4 or 8): a hidden chunk is 32 NW columns (one 32-column tile per wave in phase 1), phase 2 gives every
@@ -316,8 +322,8 @@ ffn_packed(const float* __restrict__ x, const uint32_t* __restrict__ packed1, co
   extern __shared__ __attribute__((aligned(16))) uint32_t ffn_smem[];
   constexpr int kFfnHC = 32 * NW, WJ2 = 8 / NW, NBUF = NW == 4 ? 2 : 1;
   constexpr int KC1 = kFfnD / kChunk, KC2 = kFfnHC / kChunk, BM = kFfnBM;
-  typedef uint32_t (*XsT)[KC1][BM + 1][8];        // [hi / lo][k chunk][row][16 bf16]
-  typedef uint32_t (*HsT)[2][KC2][BM + 1][8];     // [buffer][hi / lo][k chunk][row][16 bf16]
+  typedef uint32_t (*XsT)[KC1][2][kPlane];        // [hi / lo][k chunk][k half][row * 4 + word]
+  typedef uint32_t (*HsT)[2][KC2][2][kPlane];     // [buffer][hi / lo][k chunk][k half][row * 4 + word]
   XsT Xs = reinterpret_cast<XsT>(ffn_smem);
   HsT Hs = reinterpret_cast<HsT>(ffn_smem + kFfnXsWords);
 
@@ -361,7 +367,7 @@ ffn_packed(const float* __restrict__ x, const uint32_t* __restrict__ packed1, co
   // ---- phase 0: the 64 x 256 tile of x, split, into LDS (a step = 64 k = 16 pieces of 16 bytes per row) --------
   {
     const int s_piece = tid & 15, s_row0 = tid >> 4;
-    const int cc = s_piece >> 2, w2 = (s_piece & 3) * 2;
+    const int cc = s_piece >> 2, kh = (s_piece >> 1) & 1, w2 = (s_piece & 1) * 2;
     constexpr int RS = 4 * NW, NR = BM / RS;            // rows per pass, passes
     f32x4 xa[4][NR];
 #pragma unroll
@@ -385,8 +391,8 @@ ffn_packed(const float* __restrict__ x, const uint32_t* __restrict__ packed1, co
           hi[p] = (ah >> 16) | bh;
           lo[p] = ((al + 0x8000u) >> 16) | ((bl + 0x8000u) & 0xffff0000u);   // lo rounded to nearest
         }
-        *reinterpret_cast<uint2*>(&Xs[0][st * 4 + cc][s_row0 + RS * r][w2]) = make_uint2(hi[0], hi[1]);
-        *reinterpret_cast<uint2*>(&Xs[1][st * 4 + cc][s_row0 + RS * r][w2]) = make_uint2(lo[0], lo[1]);
+        *reinterpret_cast<uint2*>(&Xs[0][st * 4 + cc][kh][(s_row0 + RS * r) * 4 + w2]) = make_uint2(hi[0], hi[1]);
+        *reinterpret_cast<uint2*>(&Xs[1][st * 4 + cc][kh][(s_row0 + RS * r) * 4 + w2]) = make_uint2(lo[0], lo[1]);
       }
   }
   __syncthreads();
@@ -414,8 +420,8 @@ ffn_packed(const float* __restrict__ x, const uint32_t* __restrict__ packed1, co
       const bf16x8 wh = __builtin_bit_cast(bf16x8, wf.hi), wl = __builtin_bit_cast(bf16x8, wf.lo);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(&Xs[0][kc][i * 32 + r32][half * 4]));
-        const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(&Xs[1][kc][i * 32 + r32][half * 4]));
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(&Xs[0][kc][half][(i * 32 + r32) * 4]));
+        const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(&Xs[1][kc][half][(i * 32 + r32) * 4]));
         acc1[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, ah, acc1[i], 0, 0, 0);   // weights as A: transposed tile
         acc1[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, al, acc1[i], 0, 0, 0);
         acc1[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ah, acc1[i], 0, 0, 0);
@@ -441,9 +447,9 @@ ffn_packed(const float* __restrict__ x, const uint32_t* __restrict__ packed1, co
           hi[p] = (ah >> 16) | bh;
           lo[p] = ((al + 0x8000u) >> 16) | ((bl + 0x8000u) & 0xffff0000u);
         }
-        const int kc = wv * 2 + (g >> 1), word = 4 * (g & 1) + 2 * half;
-        *reinterpret_cast<uint2*>(&Hs[hb][0][kc][i * 32 + r32][word]) = make_uint2(hi[0], hi[1]);
-        *reinterpret_cast<uint2*>(&Hs[hb][1][kc][i * 32 + r32][word]) = make_uint2(lo[0], lo[1]);
+        const int kc = wv * 2 + (g >> 1), word = (i * 32 + r32) * 4 + 2 * half;   // k = 8 (g & 1) + 4 half .. + 3 of the chunk
+        *reinterpret_cast<uint2*>(&Hs[hb][0][kc][g & 1][word]) = make_uint2(hi[0], hi[1]);
+        *reinterpret_cast<uint2*>(&Hs[hb][1][kc][g & 1][word]) = make_uint2(lo[0], lo[1]);
       }
     }
   };
@@ -456,8 +462,8 @@ ffn_packed(const float* __restrict__ x, const uint32_t* __restrict__ packed1, co
       const W2F& wf = ring2[kc % R2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(&Hs[hb][0][kc][i * 32 + r32][half * 4]));
-        const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(&Hs[hb][1][kc][i * 32 + r32][half * 4]));
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(&Hs[hb][0][kc][half][(i * 32 + r32) * 4]));
+        const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(&Hs[hb][1][kc][half][(i * 32 + r32) * 4]));
 #pragma unroll
         for (int jn = 0; jn < WJ2; ++jn) {
           const bf16x8 wh = __builtin_bit_cast(bf16x8, wf.hi[jn]), wl = __builtin_bit_cast(bf16x8, wf.lo[jn]);
