@@ -53,3 +53,27 @@ def test_module_projection_route_on_cpu():
     mask[1, 3] = True
     y = layer._project(layer.value_proj, x, mask)
     assert torch.equal(y, layer.value_proj(x).masked_fill(mask[..., None], 0.0))
+
+
+def test_ffn_argument_errors_and_support_predicate_need_no_gpu():
+    from uninext_amd import _lib, ext
+    lib = _lib.load()
+    one = 16
+    f = lambda rows, d_model, d_ffn, x=one, p1=one, p2=one, out=one: lib.linear_hip_packed_ffn_f32(
+        x, p1, None, p2, None, None, None, None, 1e-5, 1, rows, d_model, d_ffn, out, None)
+    assert f(10, 128, 1024) == -5 and "d_model must be 256" in _lib.last_error()
+    assert f(10, 256, 192) == -5
+    assert f(-1, 256, 1024) == -2
+    assert f(10, 256, 1024, x=None) == -1
+    assert f(10, 256, 1024, p2=None) == -1
+    assert f(0, 256, 1024, x=None, p1=None, p2=None, out=None) == 0     # no rows: nothing is dereferenced
+    x = torch.zeros(4, 256)
+    w1, w2 = torch.zeros(1024, 256), torch.zeros(256, 1024)
+    assert not ext.ffn_packed_supported(x, w1, w2, (256,))               # CPU tensors never take the kernel
+    from uninext_amd.modules.encoder_layer import DeformableTransformerEncoderLayer
+    layer = DeformableTransformerEncoderLayer().eval()
+    with torch.no_grad():   # off the GPU the FFN block is the reference's composition
+        src = torch.randn(1, 5, 256)
+        want = layer.norm2(src + layer.linear2(torch.relu(layer.linear1(src))))
+        assert layer.self_attn._ffn_norm(layer.linear1, layer.linear2, src, layer.norm2) is None
+        assert torch.equal(layer.forward_ffn(src), want)
