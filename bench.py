@@ -16,15 +16,28 @@ Multi-GPU: frames shard data-parallel, every rank runs the same per-rank batch (
 collective inside the timed region; a barrier + cuda synchronize bracket it and the time is the MAX over
 ranks (all_reduce MAX over RCCL).
 
-Extra objects on the JSON line:
+Extra objects on the JSON line (all measured in this run, after the timed region unless stated):
   roofline      dominant kernel = the encoder forward launch.  achieved = algorithmic bytes per launch
                 (N*(1024*S + 2560*Lq) B) / average launch duration measured with HIP events
                 (torch.cuda.Event on the stream the kernel is launched on = torch's current stream) around
                 the encoder launches INSIDE the timed region.  peak = 8 TB/s (MI355X HBM3E spec).
+                traffic = HBM bytes per launch from the last scripted PMC pass (tools/measure_traffic.py ->
+                profiles/traffic.json), used only when that pass ran on the same kernel AND the same kernel
+                sources (sha256 of uninext_amd/csrc); null otherwise.
+  flavours      encoder-forward launch time (us) on the two other location distributions: `uniform`
+                (ops/test.py:34, no locality) and `wide` (model-like with sigma = 6 px offsets).
+  backward      BASELINE configs[4] (training step): the encoder-call and the decoder-call backward launches
+                (grad_value pre-zeroed outside the events): kernel, launch_us, algorithmic bytes
+                (N*(2048*S + 4096*Lq)), achieved GB/s, fraction of 8 TB/s, traffic (as above, or null).
+  train_step    12 forward + 12 backward calls through MSDeformAttnFunction (autograd), bs 2: ms per step.
+  ddp           world > 1 only: the DDP gradient exchange of config 5 -- fp32 all-reduce(mean) of 0.64 GB of
+                gradients in 25 MB buckets over RCCL (detectron2/engine/defaults.py:380-381 wraps the model
+                in DistributedDataParallel): alone, and overlapped with the backward launches on a side stream.
   cpu_baseline  the reference's CPU path (ms_deform_attn_core_pytorch, restated in oracle/msda_gridsample.py)
                 timed on this box's host cores on a bounded sample, rank 0 at N = 1 only.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -42,6 +55,8 @@ from uninext_amd import _lib  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ENC_LAYERS, DEC_LAYERS, BATCH = 6, 6, 2
+DDP_GRAD_BYTES = 640 * 1000 * 1000     # R50 + BERT-base fp32 gradients
+DDP_BUCKET_BYTES = 25 * 1024 * 1024    # torch DistributedDataParallel default bucket_cap_mb
 
 
 def parse_args():
@@ -49,12 +64,13 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--flavour", default="model", choices=["model", "uniform"],
+    ap.add_argument("--flavour", default="model", choices=["model", "uniform", "wide"],
                     help="sampling-location distribution (SURVEY.md 8(d)); 'model' is the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--traffic-bytes", type=float, default=None,
-                    help="HBM bytes per encoder launch from a separate rocprofv3 --pmc pass; default: the committed "
-                         "profiles/traffic.json entry for the kernel that ran (see profiles/README.md)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the flavours / backward / train_step / ddp measurements (profiling passes)")
+    ap.add_argument("--extras-only", default="",
+                    help="comma list of extras to run (flavours,backward,train,ddp); default all")
     return ap.parse_args()
 
 
@@ -89,9 +105,17 @@ def max_over_ranks(seconds, world, device="cuda"):
     return float(t.item())
 
 
-def build_inputs(flavour, rank):
-    enc = [workloads.make_inputs("encoder", flavour, batch=BATCH, seed=100 * rank + i) for i in range(ENC_LAYERS)]
-    dec = [workloads.make_inputs("decoder", flavour, batch=BATCH, seed=100 * rank + 50 + i) for i in range(DEC_LAYERS)]
+def flavour_kwargs(flavour):
+    """`wide` = the model-like pattern with sigma = 6 px offsets (closer to a trained checkpoint's spread)."""
+    if flavour == "wide":
+        return dict(flavour="model", offset_sigma=6.0)
+    return dict(flavour=flavour)
+
+
+def build_inputs(flavour, rank, device="cuda"):
+    kw = flavour_kwargs(flavour)
+    enc = [workloads.make_inputs("encoder", batch=BATCH, seed=100 * rank + i, device=device, **kw) for i in range(ENC_LAYERS)]
+    dec = [workloads.make_inputs("decoder", batch=BATCH, seed=100 * rank + 50 + i, device=device, **kw) for i in range(DEC_LAYERS)]
     return enc, dec
 
 
@@ -110,48 +134,232 @@ def run_step(enc, dec, ev=None):
         call(x)
 
 
-def committed_traffic(kernel):
-    """PMC counters cannot be collected inside the timed run; the last committed PMC pass of the same command is
-    the source (profiles/traffic.json), only used when it was taken on the kernel that ran here."""
+# -- HBM traffic from the scripted PMC pass -----------------------------------------------------------------------------
+def kernel_source_hash():
+    """sha256 over the kernel sources the library is built from: a committed PMC figure is only quoted when it
+    was taken on exactly these sources (a kernel can change and keep its name)."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "uninext_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".hpp", ".h", ".cpp")) or name == "Makefile":
+            h.update(name.encode())
+            with open(os.path.join(csrc, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(kernel, which="forward_encoder"):
+    """Bytes per launch from profiles/traffic.json (written by tools/measure_traffic.py on the GPU box), or None when
+    the entry is for another kernel or other kernel sources."""
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        return float(rec["traffic_bytes_per_launch"]) if rec.get("kernel") == kernel else None
-    except (OSError, ValueError, KeyError):
-        return None
+        e = rec["entries"][which]
+        if e.get("kernel") == kernel and rec.get("source_hash") == kernel_source_hash():
+            return float(e["traffic_bytes_per_launch"])
+    except (OSError, ValueError, KeyError, TypeError):
+        pass
+    return None
+
+
+# -- extras --------------------------------------------------------------------------------------------------------------
+def time_events(fn, reps, pre=None):
+    """Mean duration (us) of fn() over `reps` launches, each bracketed by its own pair of HIP events on the current
+    stream; `pre` runs outside the events (e.g. zeroing the accumulation target)."""
+    evs = []
+    for _ in range(reps):
+        if pre is not None:
+            pre()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    return 1e3 * sum(a.elapsed_time(b) for a, b in evs) / reps
+
+
+def measure_flavours(rank, reps=12):
+    out = {}
+    for fl in ("uniform", "wide"):
+        xs = [workloads.make_inputs("encoder", batch=BATCH, seed=100 * rank + 70 + i, **flavour_kwargs(fl)) for i in range(3)]
+        for x in xs:
+            call(x)
+        k = [0]
+
+        def one():
+            k[0] += 1
+            call(xs[k[0] % len(xs)])
+        out[fl] = {"launch_us": time_events(one, reps), "kernel": _lib.last_kernel("forward")}
+        del xs
+    return out
+
+
+def backward_call(x, go, gv, gl, ga):
+    """The C-ABI backward on pre-allocated outputs (uninext_amd.ext allocates them per call; here the launch alone
+    is what the events bracket)."""
+    import ctypes
+    lib = _lib.load()
+    N, S, M, D = x["value"].shape
+    Lq, L, P = x["loc"].shape[1], x["loc"].shape[3], x["loc"].shape[4]
+    rc = lib.msda_hip_backward_f32(go.data_ptr(), x["value"].data_ptr(), x["shapes"].data_ptr(), x["lsi"].data_ptr(),
+                                   x["loc"].data_ptr(), x["attn"].data_ptr(), N, S, M, D, L, Lq, P, gv.data_ptr(),
+                                   gl.data_ptr(), ga.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc != 0:
+        raise RuntimeError("msda_hip_backward_f32: %s [%d]" % (_lib.last_error(), rc))
+
+
+def measure_backward(enc, dec, reps=10):
+    out = {}
+    for kind, xs in (("encoder", enc), ("decoder", dec)):
+        sets = []
+        for i, x in enumerate(xs[:3]):
+            g = torch.Generator().manual_seed(900 + i)
+            go = torch.randn(x["value"].shape[0], x["loc"].shape[1], 256, generator=g).cuda()
+            sets.append((x, go, torch.zeros_like(x["value"]), torch.empty_like(x["loc"]), torch.empty_like(x["attn"])))
+        for s in sets:
+            backward_call(*s)
+        k = [0]
+
+        def pre():
+            k[0] += 1
+            sets[k[0] % len(sets)][2].zero_()
+
+        def one():
+            backward_call(*sets[k[0] % len(sets)])
+        us = time_events(one, reps, pre)
+        x = xs[0]
+        N, S = x["value"].shape[:2]
+        Lq = x["loc"].shape[1]
+        alg = workloads.algorithmic_bytes_backward(N, S, Lq)
+        kern = _lib.last_kernel("backward")
+        ach = alg / us / 1e3
+        out[kind] = {"kernel": kern, "launch_us": us, "algorithmic_bytes": alg, "achieved": ach, "unit": "GB/s",
+                     "frac": ach / HBM_PEAK_GBS, "traffic": committed_traffic(kern, "backward_" + kind),
+                     "note": "launch only; the grad_value memset (N*S*1024 B) is outside the events"}
+        del sets
+    return out
+
+
+def train_step_fn(enc, dec):
+    """12 forward + 12 backward calls through the autograd Function (what one DDP rank does per step in the op)."""
+    from uninext_amd.functions import MSDeformAttnFunction
+    sets = []
+    for i, x in enumerate(enc + dec):
+        g = torch.Generator().manual_seed(950 + i)
+        go = torch.randn(x["value"].shape[0], x["loc"].shape[1], 256, generator=g).cuda()
+        sets.append((x["value"].clone().requires_grad_(True), x["shapes"], x["lsi"], x["loc"].clone().requires_grad_(True),
+                     x["attn"].clone().requires_grad_(True), go))
+
+    def step():
+        outs = []
+        for v, sh, lsi, loc, attn, go in sets:
+            v.grad = loc.grad = attn.grad = None
+            outs.append(MSDeformAttnFunction.apply(v, sh, lsi, loc, attn, 64))
+        for o, s in zip(reversed(outs), reversed(sets)):
+            o.backward(s[5])
+    return step
+
+
+def measure_train_step(enc, dec, world, reps=5):
+    step = train_step_fn(enc, dec)
+    step()
+    barrier(world)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        step()
+    torch.cuda.synchronize()
+    barrier(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world) / reps
+    return {"ms_per_step": 1e3 * dt, "frames_per_s": world * BATCH / dt,
+            "workload": "BASELINE configs[4] per-GPU share: bs 2, 6 encoder + 6 decoder MSDeformAttn forward AND "
+                        "backward calls through MSDeformAttnFunction (autograd, incl. output allocation + memsets)",
+            "kernels": {"forward": _lib.last_kernel("forward"), "backward_last": _lib.last_kernel("backward")}}
+
+
+def measure_ddp(enc, dec, world, reps=5):
+    """fp32 gradient all-reduce (mean) in DDP-sized buckets over RCCL, alone and overlapped with the op's backward
+    launches (side stream), as DistributedDataParallel overlaps it with autograd."""
+    import torch.distributed as dist
+    n_el = DDP_BUCKET_BYTES // 4
+    n_buckets = (DDP_GRAD_BYTES + DDP_BUCKET_BYTES - 1) // DDP_BUCKET_BYTES
+    buckets = [torch.randn(n_el, device="cuda") for _ in range(n_buckets)]
+    comm = torch.cuda.Stream()
+
+    def allreduce_all():
+        for b in buckets:
+            dist.all_reduce(b, op=dist.ReduceOp.SUM)
+            b.mul_(1.0 / world)
+
+    def timed(fn):
+        fn()
+        barrier(world)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        barrier(world)
+        return 1e3 * max_over_ranks(time.perf_counter() - t0, world) / reps
+
+    step = train_step_fn(enc, dec)
+
+    def overlapped():
+        comm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(comm):
+            allreduce_all()
+        step()
+        torch.cuda.current_stream().wait_stream(comm)
+
+    ar = timed(allreduce_all)
+    st = timed(step)
+    ov = timed(overlapped)
+    nbytes = n_buckets * DDP_BUCKET_BYTES
+    return {"allreduce_ms": ar, "bytes": nbytes, "buckets": n_buckets, "bucket_bytes": DDP_BUCKET_BYTES,
+            "busbw_GBs": 2.0 * (world - 1) / world * nbytes / (ar * 1e-3) / 1e9,
+            "op_fwd_bwd_ms": st, "overlapped_ms": ov, "backend": "nccl (RCCL over xGMI)"}
 
 
 def cpu_baseline(flavour):
     """Bounded sample of the same workload on the host: one encoder call and one decoder call of the
     reference's grid_sample path (N = 2); a step is 6 of each.  grid_sample's OpenMP scaling collapses when
-    oversubscribed, so two thread counts are tried (all logical cores, and 64 when the box has more) and the
-    faster one is reported together with the thread count it used."""
+    oversubscribed, so a one-run probe picks the thread count (all logical cores, 64, 32) and the timed runs
+    (>= 10 per call kind, median) use the fastest one; the count is reported as `cores`."""
     from oracle.msda_gridsample import msda_gridsample
     ncpu = os.cpu_count() or 1
     inputs = {}
     for kind in ("encoder", "decoder"):
-        x = workloads.make_inputs(kind, flavour, batch=BATCH, seed=7, device="cpu")
+        x = workloads.make_inputs(kind, batch=BATCH, seed=7, device="cpu", **flavour_kwargs(flavour))
         inputs[kind] = (x, [tuple(r) for r in x["shapes"].tolist()])
-    best = None
-    for threads in sorted({ncpu, min(ncpu, 64)}, reverse=True):
-        torch.set_num_threads(threads)
-        per_step = 0.0
+
+    def run(kind):
+        x, shapes = inputs[kind]
+        t0 = time.perf_counter()
         with torch.no_grad():
-            for kind, layers in (("encoder", ENC_LAYERS), ("decoder", DEC_LAYERS)):
-                x, shapes = inputs[kind]
-                msda_gridsample(x["value"], shapes, x["loc"], x["attn"])
-                ts = []
-                for _ in range(3):
-                    t0 = time.perf_counter()
-                    msda_gridsample(x["value"], shapes, x["loc"], x["attn"])
-                    ts.append(time.perf_counter() - t0)
-                per_step += layers * sorted(ts)[1]
-        if best is None or per_step < best[0]:
-            best = (per_step, threads)
-    per_step, threads = best
+            msda_gridsample(x["value"], shapes, x["loc"], x["attn"])
+        return time.perf_counter() - t0
+
+    probe = {}
+    for threads in sorted({ncpu, min(ncpu, 64), min(ncpu, 32)}):
+        torch.set_num_threads(threads)
+        run("encoder")
+        probe[threads] = run("encoder")
+        if probe[threads] > 4.0 * min(probe.values()):
+            break           # oversubscribed: more threads only get slower
+    threads = min(probe, key=probe.get)
+    torch.set_num_threads(threads)
+    runs = 10 if probe[threads] < 2.0 else 5
+    per_step, med = 0.0, {}
+    for kind, layers in (("encoder", ENC_LAYERS), ("decoder", DEC_LAYERS)):
+        run(kind)
+        ts = sorted(run(kind) for _ in range(runs))
+        med[kind] = 0.5 * (ts[(runs - 1) // 2] + ts[runs // 2])
+        per_step += layers * med[kind]
     return {"value": BATCH / per_step, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": "median of 3 runs (after 1 warm-up) of ONE encoder call and ONE decoder call at N=2, "
-                      "x6 each per step; oracle/msda_gridsample.py (= ms_deform_attn_core_pytorch), fp32, "
-                      "torch.set_num_threads(%d) of %d logical cores (faster of the thread counts tried)" % (threads, ncpu)}
+            "sample": "median of %d timed runs (after 1 warm-up) of ONE encoder call (%.3f s) and ONE decoder call "
+                      "(%.4f s) at N=2, x6 each per step; oracle/msda_gridsample.py (= ms_deform_attn_core_pytorch), "
+                      "fp32, torch.set_num_threads(%d) of %d logical cores (fastest of the probed counts %s)"
+                      % (runs, med["encoder"], med["decoder"], threads, ncpu, sorted(probe))}
 
 
 def main():
@@ -177,6 +385,18 @@ def main():
     torch.cuda.synchronize()
     barrier(world)
     elapsed = max_over_ranks(time.perf_counter() - t0, world)
+
+    extras = {}
+    want = set(args.extras_only.split(",")) if args.extras_only else {"flavours", "backward", "train", "ddp"}
+    if not args.no_extras:   # every rank takes part (collectives inside), rank 0 reports
+        if "flavours" in want:
+            extras["flavours"] = measure_flavours(rank)
+        if "backward" in want:
+            extras["backward"] = measure_backward(enc, dec)
+        if "train" in want:
+            extras["train_step"] = measure_train_step(enc, dec, world)
+        if "ddp" in want and world > 1:
+            extras["ddp"] = measure_ddp(enc, dec, world)
 
     if rank == 0:
         enc_ms = sum(a.elapsed_time(b) for a, b in events) / (args.steps * ENC_LAYERS)  # per encoder launch
@@ -206,10 +426,13 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": args.traffic_bytes if args.traffic_bytes is not None else committed_traffic(enc_kernel),
+                "traffic": committed_traffic(enc_kernel, "forward_encoder") if args.flavour == "model" else None,
+                "traffic_source": "profiles/traffic.json (tools/measure_traffic.py; kernel name + source hash %s must match)"
+                                  % kernel_source_hash(),
                 "kernel": enc_kernel, "launch_us": 1e3 * enc_ms, "algorithmic_bytes": alg_bytes,
             },
         }
+        out.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.flavour)
         print(json.dumps(out), flush=True)

@@ -118,6 +118,36 @@ int msda_hip_forward_fused_hm_f32(const float* value_head_major, const int64_t* 
                                   float* output, void* stream);
 
 /*
+ * Host-pointer (CPU) variants -- SURVEY.md 8(b)(i).  Same argument order and tensor layouts as the device entry
+ * points, but every pointer is HOST memory and the work runs on `num_threads` host threads (<= 0: all hardware
+ * threads).  The reference has no CPU implementation (ops/src/cpu/ms_deform_attn_cpu.cpp:17-41 are AT_ERROR stubs and
+ * ops/src/ms_deform_attn.h:35-38 raises for CPU tensors); these cover BASELINE configs[0], the model's plumbing on a
+ * GPU-less box, which the reference can only run through the grid_sample composition
+ * ms_deform_attn_core_pytorch (ops/functions/ms_deform_attn_func.py:43-63).  Synchronous; no HIP call is made, so
+ * they work without a GPU.  Backward ACCUMULATES into grad_value (zero it first) and overwrites the other two, like
+ * the device entry points; its summation order is deterministic (one thread per (image, head) slice of grad_value).
+ * Implemented in uninext_amd/csrc/msda_host.cpp.
+ */
+int msda_host_forward_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                          const float* sampling_loc, const float* attn_weight, int batch, int spatial_size,
+                          int num_heads, int channels, int num_levels, int num_query, int num_point,
+                          float* output, int num_threads);
+int msda_host_forward_f64(const double* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                          const double* sampling_loc, const double* attn_weight, int batch, int spatial_size,
+                          int num_heads, int channels, int num_levels, int num_query, int num_point,
+                          double* output, int num_threads);
+int msda_host_backward_f32(const float* grad_output, const float* value, const int64_t* spatial_shapes,
+                           const int64_t* level_start_index, const float* sampling_loc, const float* attn_weight,
+                           int batch, int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                           int num_point, float* grad_value, float* grad_sampling_loc, float* grad_attn_weight,
+                           int num_threads);
+int msda_host_backward_f64(const double* grad_output, const double* value, const int64_t* spatial_shapes,
+                           const int64_t* level_start_index, const double* sampling_loc, const double* attn_weight,
+                           int batch, int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                           int num_point, double* grad_value, double* grad_sampling_loc, double* grad_attn_weight,
+                           int num_threads);
+
+/*
  * Kernel selection (tuning / A-B measurement only; results are identical up to fp32
  * summation order).  which: 0 = forward, 1 = backward.  variant: 0 = automatic (default),
  * 1 = generic one-thread-per-output kernel, 2 = lane-group gather kernel, higher numbers as

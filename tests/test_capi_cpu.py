@@ -1,5 +1,6 @@
 """CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/msda_hip.h declares.
-No compute call is made here (there is no GPU in the build container)."""
+No DEVICE compute call is made here (there is no GPU in the build container); the host-pointer variants
+(msda_host_*) are exercised by tests/test_host_variants_cpu.py."""
 import ctypes
 import os
 import re
@@ -19,7 +20,7 @@ def lib():
 def declared_functions():
     text = open(os.path.join(ROOT, "include", "msda_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(msda_hip_\w+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(msda_(?:hip|host)_\w+)\s*\(", text)))
 
 
 def test_header_declares_the_boundary():

@@ -9,15 +9,26 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_cpu_tensors_are_rejected_like_the_reference():
-    """ops/src/ms_deform_attn.h:35-38: CPU input -> 'Not implemented on the CPU' (no silent fallback)."""
+def test_cpu_tensors_take_the_host_variants_or_the_reference_error(monkeypatch):
+    """ops/src/ms_deform_attn.h:35-38 raises 'Not implemented on the CPU'.  Here CPU tensors are served by the
+    host-pointer variants of the C ABI (msda_host_*); MSDA_HIP_STRICT_DEVICE=1 restores the
+    reference's error.  The device-only fused entry point keeps raising."""
     import MultiScaleDeformableAttention as MSDA
-    v = torch.zeros(1, 2, 1, 4)
-    args = (v, torch.tensor([[1, 2]]), torch.tensor([0]), torch.zeros(1, 1, 1, 1, 1, 2), torch.zeros(1, 1, 1, 1, 1))
+    from uninext_amd import ext
+    v = torch.ones(1, 2, 1, 4)
+    args = (v, torch.tensor([[1, 2]]), torch.tensor([0]), torch.full((1, 1, 1, 1, 1, 2), 0.5), torch.ones(1, 1, 1, 1, 1))
+    out = MSDA.ms_deform_attn_forward(*args, 64)
+    assert out.shape == (1, 1, 4) and torch.allclose(out, torch.ones(1, 1, 4))
+    gv, gl, ga = MSDA.ms_deform_attn_backward(*args, torch.ones(1, 1, 4), 64)
+    assert gv.shape == v.shape and abs(float(gv.sum()) - 4.0) < 1e-6 and abs(float(ga) - 4.0) < 1e-6
+    monkeypatch.setattr(ext, "STRICT_DEVICE", True)
     with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
         MSDA.ms_deform_attn_forward(*args, 64)
     with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
         MSDA.ms_deform_attn_backward(*args, torch.zeros(1, 1, 4), 64)
+    monkeypatch.setattr(ext, "STRICT_DEVICE", False)
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        ext.ms_deform_attn_forward_fused(v, args[1], args[2], torch.zeros(1, 1, 1, 2), torch.zeros(1, 1, 2), torch.zeros(1, 1, 1), 1)
 
 
 def test_module_name_and_exports_match_the_reference_extension():

@@ -36,7 +36,8 @@ def main():
     ap.add_argument("--variants-fwd", default="")
     ap.add_argument("--variants-bwd", default="")
     ap.add_argument("--kinds", default="encoder,decoder")
-    ap.add_argument("--flavours", default="model,uniform")
+    ap.add_argument("--flavours", default="model,uniform,wide",
+                    help="model (init-time offsets, sigma 1 px), uniform (ops/test.py:34), wide (model-like, sigma 6 px)")
     ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--no-bwd", action="store_true")
     ap.add_argument("--sigma", type=float, default=1.0)
@@ -48,7 +49,8 @@ def main():
     vb = [int(v) for v in args.variants_bwd.split(",") if v] or [1, 2, 3]
     for kind in args.kinds.split(","):
         for flavour in args.flavours.split(","):
-            xs = [workloads.make_inputs(kind, flavour, batch=args.batch, seed=1 + r, offset_sigma=args.sigma,
+            fl, sigma = ("model", 6.0) if flavour == "wide" else (flavour, args.sigma)
+            xs = [workloads.make_inputs(kind, fl, batch=args.batch, seed=1 + r, offset_sigma=sigma,
                                         far_fraction=args.far) for r in range(args.rotate)]
             x = xs[0]
             N, S = x["value"].shape[:2]

@@ -12,6 +12,7 @@ EXPORTS = (
     "msda_hip_abi_version", "msda_hip_last_error",
     "msda_hip_forward_f32", "msda_hip_forward_f64", "msda_hip_backward_f32", "msda_hip_backward_f64",
     "msda_hip_forward_fused_f32", "msda_hip_forward_fused_hm_f32",
+    "msda_host_forward_f32", "msda_host_forward_f64", "msda_host_backward_f32", "msda_host_backward_f64",
     "msda_hip_set_variant", "msda_hip_get_variant", "msda_hip_variant_name", "msda_hip_last_kernel",
 )
 
@@ -49,6 +50,10 @@ def load():
         f.argtypes, f.restype = [p, p, p, p, p, i, i, i, i, i, i, i, p, p], i
         g = getattr(lib, "msda_hip_backward_" + suf)
         g.argtypes, g.restype = [p, p, p, p, p, p, i, i, i, i, i, i, i, p, p, p, p], i
+        fh = getattr(lib, "msda_host_forward_" + suf)     # host pointers; last argument: number of threads
+        fh.argtypes, fh.restype = [p, p, p, p, p, i, i, i, i, i, i, i, p, i], i
+        gh = getattr(lib, "msda_host_backward_" + suf)
+        gh.argtypes, gh.restype = [p, p, p, p, p, p, i, i, i, i, i, i, i, p, p, p, i], i
     lib.msda_hip_forward_fused_f32.argtypes = [p, p, p, p, i, p, p, i, i, i, i, i, i, i, p, p]
     lib.msda_hip_forward_fused_f32.restype = i
     lib.msda_hip_forward_fused_hm_f32.argtypes = lib.msda_hip_forward_fused_f32.argtypes

@@ -13,6 +13,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ext
+from ._cache import CachedModuleMixin, packed_weight
 
 
 def _use_hip(x, conv):
@@ -23,13 +24,7 @@ def _use_hip(x, conv):
 
 def _packed_weight(conv):
     """Split-bf16 packed copy of conv.weight, cached on the module and rebuilt when the parameter changes."""
-    w = conv.weight
-    key = (w.data_ptr(), w._version, str(w.device))
-    cache = conv.__dict__.get("_msda_packed")
-    if cache is None or cache[0] != key:
-        cache = (key, ext.patch_embed_pack_weight(w.detach().contiguous()))
-        conv.__dict__["_msda_packed"] = cache
-    return cache[1]
+    return packed_weight(conv, ext.patch_embed_pack_weight)
 
 
 def _hip_conv(x, conv, channels_last, exact):
@@ -48,7 +43,7 @@ def patch_conv2d(x, conv, exact=False):
     return conv(x)
 
 
-class PatchEmbed(nn.Module):
+class PatchEmbed(CachedModuleMixin, nn.Module):
     """Image to Patch Embedding (backbone/utils.py:160-186): same constructor, same `proj` parameter names."""
 
     exact_fp32 = False   # True: exact-fp32 MFMA kernel instead of the split-bf16 path

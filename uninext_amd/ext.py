@@ -7,12 +7,20 @@ raise "Not implemented on the CPU") and ops/src/cuda/ms_deform_attn_cuda.cu:28-5
 (contiguity / device / im2col_step checks), :54 and :121-123 (output allocation).
 """
 import ctypes
+import os
 
 import torch
 
 from . import _lib
 
 _SUFFIX = {torch.float32: "f32", torch.float64: "f64"}
+# CPU tensors: the reference raises "Not implemented on the CPU" (ops/src/ms_deform_attn.h:35-38).  This library has
+# host-pointer variants of the operator (include/msda_hip.h: msda_host_*, csrc/msda_host.cpp; SURVEY.md 8(b)(i)), so
+# CPU tensors are served by them -- BASELINE configs[0], the model's plumbing on a GPU-less box, then runs through the
+# same `MSDeformAttnFunction` instead of ms_deform_attn_core_pytorch.  MSDA_HIP_STRICT_DEVICE=1 restores the
+# reference's error.  GPU tensors never take this route: they go to the HIP kernels or fail loudly.
+STRICT_DEVICE = os.environ.get("MSDA_HIP_STRICT_DEVICE", "0") == "1"
+HOST_THREADS = int(os.environ.get("MSDA_HOST_THREADS", "0"))   # 0: all hardware threads
 
 
 def _check(name, t, dev):
@@ -36,9 +44,30 @@ def _dims(value, spatial_shapes, sampling_loc, im2col_step):
     return batch, spatial_size, num_heads, channels, num_levels, num_query, num_point
 
 
+def _host_args(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, extra=()):
+    """Validation of an all-CPU call (same contiguity / dtype rules as the device path)."""
+    if STRICT_DEVICE:
+        raise RuntimeError("Not implemented on the CPU")  # ops/src/ms_deform_attn.h:38
+    if value.dtype not in _SUFFIX:
+        raise RuntimeError("ms_deform_attn: unsupported dtype %s (float32/float64 only)" % value.dtype)
+    named = (("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
+             ("sampling_loc", sampling_loc), ("attn_weight", attn_weight)) + tuple(extra)
+    for name, t in named:
+        if not t.is_contiguous():
+            raise RuntimeError("%s tensor has to be contiguous" % name)
+        if t.is_cuda:
+            raise RuntimeError("%s is on %s but value is on the CPU" % (name, t.device))
+    for name, t in (("sampling_loc", sampling_loc), ("attn_weight", attn_weight)) + tuple(extra):
+        if t.dtype != value.dtype:
+            raise RuntimeError("%s has dtype %s, value has %s" % (name, t.dtype, value.dtype))
+    if spatial_shapes.dtype != torch.int64 or level_start_index.dtype != torch.int64:
+        raise RuntimeError("spatial_shapes and level_start_index must be int64")
+    return _lib.load(), _SUFFIX[value.dtype]
+
+
 def _prep(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, extra=()):
     if not value.is_cuda:
-        raise RuntimeError("Not implemented on the CPU")  # ops/src/ms_deform_attn.h:38
+        raise RuntimeError("Not implemented on the CPU")  # ops/src/ms_deform_attn.h:38 (fused / device-only entry points)
     if value.dtype not in _SUFFIX:
         raise RuntimeError("ms_deform_attn: unsupported dtype %s (float32/float64 only)" % value.dtype)
     dev = value.device
@@ -62,6 +91,16 @@ def _raise(rc):
 
 
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
+    if not value.is_cuda:   # host-pointer variant of the C ABI
+        lib, suf = _host_args(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+        N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, sampling_loc, im2col_step)
+        out = torch.empty((N, Lq, M * D), dtype=value.dtype)
+        rc = getattr(lib, "msda_host_forward_" + suf)(
+            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
+            attn_weight.data_ptr(), N, S, M, D, L, Lq, P, out.data_ptr(), HOST_THREADS)
+        if rc != 0:
+            _raise(rc)
+        return out
     lib, suf = _prep(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
     N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, sampling_loc, im2col_step)
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)  # kernel writes every element
@@ -77,6 +116,18 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
 
 def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output,
                             im2col_step):
+    if not value.is_cuda:   # host-pointer variant of the C ABI
+        lib, suf = _host_args(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                              extra=(("grad_output", grad_output),))
+        N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, sampling_loc, im2col_step)
+        grad_value, grad_loc, grad_attn = torch.zeros_like(value), torch.empty_like(sampling_loc), torch.empty_like(attn_weight)
+        rc = getattr(lib, "msda_host_backward_" + suf)(
+            grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+            sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P, grad_value.data_ptr(),
+            grad_loc.data_ptr(), grad_attn.data_ptr(), HOST_THREADS)
+        if rc != 0:
+            _raise(rc)
+        return [grad_value, grad_loc, grad_attn]
     lib, suf = _prep(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
                      extra=(("grad_output", grad_output),))
     N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, sampling_loc, im2col_step)

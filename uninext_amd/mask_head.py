@@ -16,6 +16,7 @@ import torch
 import torch.nn.functional as F
 
 from . import ext as _ext
+from ._cache import CachedModuleMixin, packed_weight
 
 DYNAMIC_MASK_CHANNELS = 8   # ddetrs_dn.py:46
 
@@ -116,13 +117,7 @@ def _expand(tensor, length):
 
 def _packed_weight(conv):
     """Split-bf16 packed copy of conv.weight, cached on the module and rebuilt when the parameter changes."""
-    w = conv.weight
-    key = (w.data_ptr(), w._version, str(w.device))
-    cache = conv.__dict__.get("_msda_packed")
-    if cache is None or cache[0] != key:
-        cache = (key, _ext.conv3x3_pack_weight(w.detach().contiguous()))
-        conv.__dict__["_msda_packed"] = cache
-    return cache[1]
+    return packed_weight(conv, _ext.conv3x3_pack_weight)
 
 
 def conv3x3_relu(x, conv, exact=False):
@@ -140,7 +135,7 @@ def conv3x3_relu(x, conv, exact=False):
     return F.relu(conv(x))
 
 
-class MaskHeadSmallConv(torch.nn.Module):
+class MaskHeadSmallConv(CachedModuleMixin, torch.nn.Module):
     """Simple convolutional head, FPN-style up-sampling (ddetrs_dn.py:923-1031): same constructor arguments, same
     parameter names (lay1..lay4, jia_dcn, adapter1..3), same initialisation, same forward; the five
     `F.relu(self.layN(...))` steps go through conv3x3_relu.  `use_raft` is not covered (False in every shipped

@@ -11,9 +11,12 @@ cost is built from the same torch operations in the same order (a different summ
 in the assignment), pinned by reference-minted fixtures (tests/golden/matcher_*.npz, tests/test_matcher_cpu.py).
 
 What differs from the reference: the focal cost table (pos - neg) is built once instead of inside the per-target
-loop, boxes are converted once, and the code is device-agnostic (no `.cuda()`); the linear-sum-assignment itself is
-SciPy's (`scipy.optimize.linear_sum_assignment`, any SciPy > 1.5.1 as in the reference's setup.py:185) on the host,
-exactly where the reference runs it (matcher.py:499-502).
+loop, boxes are converted once, and the code is device-agnostic (no `.cuda()`).  The linear-sum-assignment: for GPU
+inputs (`device_lsap = True`, the default) it runs ON THE DEVICE (include/lsap_hip.h, csrc/lsap.hip: SciPy's
+shortest-augmenting-path algorithm with SciPy's tie rules, index-for-index equal to it, tests/test_lsap_gpu.py) and
+only the min(Q, G) index pairs come back to the host; for CPU inputs, or with `device_lsap = False`, it is SciPy's
+`scipy.optimize.linear_sum_assignment` (any SciPy > 1.5.1 as in the reference's setup.py:185) on the host, exactly
+where the reference runs it (matcher.py:499-502).
 """
 import torch
 from scipy.optimize import linear_sum_assignment

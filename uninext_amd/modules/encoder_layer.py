@@ -16,6 +16,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import ext as MSDA
+from .._cache import CachedModuleMixin
 from .ms_deform_attn import MSDeformAttn
 
 
@@ -29,7 +30,7 @@ def _get_activation_fn(activation):
     raise RuntimeError(F"activation should be relu/gelu, not {activation}.")
 
 
-class DeformableTransformerEncoderLayer(nn.Module):
+class DeformableTransformerEncoderLayer(CachedModuleMixin, nn.Module):
     fuse_ffn = True   # inference: linear1 + ReLU + linear2 + residual + norm2 as one kernel (include/linear_hip.h)
 
     def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4, n_heads=8, n_points=4):

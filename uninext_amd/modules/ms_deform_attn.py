@@ -25,6 +25,7 @@ from torch import nn
 from torch.nn.init import constant_, xavier_uniform_
 
 from .. import ext as MSDA
+from .._cache import CachedModuleMixin, CheckedOnce, packed_weight
 from ..functions import MSDeformAttnFunction
 
 
@@ -34,7 +35,7 @@ def _is_power_of_2(n):
     return n != 0 and (n & (n - 1)) == 0
 
 
-class MSDeformAttn(nn.Module):
+class MSDeformAttn(CachedModuleMixin, nn.Module):
     fuse_prologue = os.environ.get("UNINEXT_AMD_NO_FUSED", "0") != "1"
     fast_linear = os.environ.get("UNINEXT_AMD_EXACT_LINEAR", "0") != "1"
 
@@ -73,22 +74,22 @@ class MSDeformAttn(nn.Module):
         constant_(self.output_proj.bias.data, 0.0)
 
     # -- argument check of :93 without a device->host sync per call -----------------------------------------
-    _shape_checks = {}
+    _shape_checks = CheckedOnce()
 
     @classmethod
     def _check_shapes(cls, spatial_shapes, len_in):
         """`assert (H * W).sum() == Len_in` (ops/modules/ms_deform_attn.py:93).  On a GPU tensor the comparison is a
-        host sync; it is done once per (tensor, version, Len_in) and skipped while a HIP graph is being captured."""
+        host sync: it is done once per shapes TENSOR OBJECT (weak reference + version, so a new tensor that happens to
+        reuse a freed address is checked again; inference tensors carry no version and are keyed by identity alone)
+        and skipped while a HIP graph is being captured.  A fresh shapes tensor per forward -- what Deformable-DETR
+        builds -- is checked on every call, exactly as in the reference."""
         if spatial_shapes.is_cuda:
             if torch.cuda.is_current_stream_capturing():
                 return
-            key = (spatial_shapes.data_ptr(), spatial_shapes._version, str(spatial_shapes.device), int(len_in))
-            if cls._shape_checks.get(key):
+            if cls._shape_checks.hit(spatial_shapes, int(len_in)):
                 return
-            if len(cls._shape_checks) > 64:
-                cls._shape_checks.clear()
             assert (spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum() == len_in
-            cls._shape_checks[key] = True
+            cls._shape_checks.add(spatial_shapes, int(len_in))
             return
         assert (spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum() == len_in
 
@@ -98,14 +99,9 @@ class MSDeformAttn(nn.Module):
         return self.fast_linear and not needs_grad and x.is_contiguous() and MSDA.linear_packed_supported(x, lin.weight)
 
     def _packed(self, lin):
-        """Packed copy of lin.weight (include/linear_hip.h), cached on the Linear, rebuilt when the parameter changes."""
-        w = lin.weight
-        key = (w.data_ptr(), w._version, str(w.device))
-        cache = lin.__dict__.get("_msda_packed")
-        if cache is None or cache[0] != key:
-            cache = (key, MSDA.linear_pack_weight(w.detach().contiguous()))
-            lin.__dict__["_msda_packed"] = cache
-        return cache[1]
+        """Packed copy of lin.weight (include/linear_hip.h), cached on the Linear, rebuilt when the parameter changes
+        (uninext_amd/_cache.py: version counter, train()/eval(), load_state_dict, or invalidate_packed())."""
+        return packed_weight(lin, MSDA.linear_pack_weight)
 
     def _project_norm(self, lin, x, residual, norm):
         """`norm(residual + lin(x))`: at inference the add and the LayerNorm run in the Linear's epilogue."""
@@ -158,6 +154,13 @@ class MSDeformAttn(nn.Module):
                 + offsets / P * reference_points[:, :, None, :, None, 2:] * 0.5
         return MSDeformAttnFunction.apply(value, shapes, level_start, locations, weights, self.im2col_step)
 
+    def _records_grad(self, *tensors):
+        """True when autograd would record through this layer: the fused / head-major sampling entry points have no
+        backward, so ANY trainable parameter of the layer (e.g. sampling_offsets fine-tuned on a frozen value_proj)
+        or any input that carries grad sends the call down the reference's differentiable data flow."""
+        return torch.is_grad_enabled() and (any(t is not None and t.requires_grad for t in tensors)
+                                            or any(p.requires_grad for p in self.parameters()))
+
     def _can_fuse(self, value, reference_points, offsets, logits):
         if not self.fuse_prologue or not MSDA.fused_forward_supported(value, reference_points, self.n_levels,
                                                                       self.n_points):
@@ -187,7 +190,7 @@ class MSDeformAttn(nn.Module):
         # that way (a head's pixels 128 bytes apart instead of 1 KB: 6-15 % off the sampling kernel)
         head_major = (self.fuse_prologue and self._fast_ok(self.value_proj, input_flatten) and head_dim == 32
                       and MSDA.fused_forward_hm_supported((head_dim,), self.n_levels, self.n_points, query.shape[1])
-                      and not (torch.is_grad_enabled() and (query.requires_grad or reference_points.requires_grad))
+                      and not self._records_grad(query, reference_points, input_flatten)
                       and reference_points.is_contiguous())
         value = self._project(self.value_proj, input_flatten, input_padding_mask, Len_in if head_major else 0)
         if not head_major:
