@@ -18,7 +18,7 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LEVELS = ((20, 27), (10, 14), (5, 7), (3, 4))     # encoder-style call: every pixel is a query -> tiled backward
+LEVELS = ((24, 33), (12, 17), (6, 9), (3, 5))    # S = 1065: encoder-style call (Lq == S >= 1024) -> the tiled backward
 
 
 def _inputs(device):

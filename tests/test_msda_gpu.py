@@ -636,3 +636,28 @@ def test_module_inference_uses_fused_kernel_and_matches_autograd_path(ref_dim, d
     assert lib.last_kernel("forward") != "msda_fwd_fused"
     out.sum().backward()
     assert q2.grad is not None and torch.isfinite(q2.grad).all()
+
+
+def test_module_under_inference_mode(dev, api):
+    """torch.inference_mode(): tensors carry no version counter (`_version` raises).  The module -- shapes tensor built
+    inside the forward, parameters loaded under inference_mode -- must run as it does under no_grad."""
+    from uninext_amd.modules import MSDeformAttn
+    from uninext_amd.workloads import encoder_reference_points
+    torch.manual_seed(2)
+    levels = ((40, 53), (20, 27), (10, 14), (5, 7))          # S = 2835 >= 1024: the encoder-sized fused path
+    S = sum(h * w for h, w in levels)
+    src = torch.randn(2, S, 256, device=dev)
+    ref = encoder_reference_points(levels, dev)[None, :, None, :].expand(2, S, 4, 2).contiguous()
+    with torch.inference_mode():
+        m = MSDeformAttn(256, 4, 8, 4).to(dev)               # inference parameters
+        sh = torch.as_tensor(levels, dtype=torch.long, device=dev)
+        lsi = torch.cat((sh.new_zeros((1,)), sh.prod(1).cumsum(0)[:-1]))
+        a = m(src, ref, src, sh, lsi, None)
+        b = m(src, ref, src, sh, lsi, None)                  # cached packed weights, cached shape check
+    m2 = MSDeformAttn(256, 4, 8, 4).to(dev)
+    m2.load_state_dict({k: v.clone() for k, v in m.state_dict().items()})
+    sh2 = torch.as_tensor(levels, dtype=torch.long, device=dev)
+    with torch.no_grad():
+        c = m2(src, ref, src, sh2, torch.cat((sh2.new_zeros((1,)), sh2.prod(1).cumsum(0)[:-1])), None)
+    assert torch.equal(a, b)
+    assert float((a - c).abs().max()) < 1e-6
