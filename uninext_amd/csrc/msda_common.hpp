@@ -99,7 +99,7 @@ inline int ensure_dynamic_lds(const void* kernel, int bytes, std::atomic<uint64_
 
 // Variant numbering shared with include/msda_hip.h.
 enum Variant { kAuto = 0, kGeneric = 1, kLaneGroup = 2, kTiled = 3, kTiledL0 = 4, kTiledL0Big = 5, kLaneGroupCL = 6,
-               kLaneGroupL3 = 7, kLaneGroupP = 8, kNumVariants = 9 };
+               kLaneGroupL3 = 7, kLaneGroupP = 8, kWin = 9, kNumVariants = 10 };
 
 // msda_fwd.hip: forward with the MSDeformAttn prologue (softmax + sampling locations) fused in.
 bool fused_forward_ok(const Dims& d, int ref_dim);
@@ -113,6 +113,11 @@ bool tiled_backward_ok(const Dims& d);
 int launch_backward_tiled(const float* grad_out, const float* value, const int64_t* shapes, const int64_t* lsi,
                           const float* loc, const float* attn, const Dims& d, float* grad_value, float* grad_loc,
                           float* grad_attn, hipStream_t stream);
+
+// msda_fwd_win.hip: encoder forward with LDS windows on all four levels (fp32, D = 32, L = P = 4, Lq == S).
+bool win_forward_ok(const Dims& d);
+int launch_forward_win(const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc, const float* attn,
+                       const Dims& d, float* out, hipStream_t stream);
 
 // msda_fwd_tiled.hip: LDS-tiled encoder forward (fp32, D = 32, Lq == S).
 bool tiled_forward_ok(const Dims& d);

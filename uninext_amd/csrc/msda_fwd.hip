@@ -938,6 +938,11 @@ int launch_forward<float>(int variant, const float* value, const int64_t* shapes
   // kbench A/B (profiles/): msda_fwd_lg3 beats msda_fwd_lanegroup by 14-20 % from ~1000 queries on; the tiled and
   // lgcl kernels lose and stay opt-in
   if (variant == kAuto) variant = lg3_ok(d) ? kLaneGroupL3 : (lg ? kLaneGroup : kGeneric);
+  if (variant == kWin && !win_forward_ok(d)) variant = lg3_ok(d) ? kLaneGroupL3 : kLaneGroup;
+  if (variant == kWin) {
+    *kernel_name = "msda_fwd_win";
+    return launch_forward_win(value, shapes, lsi, loc, attn, d, out, stream);
+  }
   if (variant == kLaneGroupL3 && !lg3_ok(d)) variant = kLaneGroup;
   if (variant == kLaneGroupL3) {
     *kernel_name = "msda_fwd_lg3";
