@@ -18,11 +18,11 @@
 //                Staging is LDS-DMA (`buffer_load_dwordx4 ... lds`): no registers, no ds_write, and it stays in
 //                flight while the wave does other work.
 //   lane roles = a QUAD of lanes owns one (query, head) pair; lane k of the quad prepares the four points of level
-//                k (x first, then y; corner weights with the attention weight folded in) and accumulates channels
-//                8k .. 8k+7.  Prepared samples never touch memory: the consumer lanes read them straight out of the
+//                k (x first, then y; corner weights with the attention weight folded in) and accumulates the
+//                channels of the 16-byte pieces k and k + 4 of a pixel.  Prepared samples never touch memory: the consumer lanes read them straight out of the
 //                preparing lane's registers with DPP quad_perm broadcasts (folded into the FMA / address add).
-//   LDS banks  = a ds_read_b128 is served in four groups of 16 lanes = 4 quads; a quad reads 4 x 16 B spaced 32 B
-//                apart = 16 of a pixel's 32 banks.  The four quads of a group take four different (16-byte half,
+//   LDS banks  = a ds_read_b128 is served in four groups of 16 lanes = 4 quads; a quad reads 64 contiguous
+//                bytes = 16 of a pixel's 32 banks.  The four quads of a group take four different (16-byte half,
 //                pixel parity) orders over the two x-adjacent corners of a bilinear row, so that in every
 //                instruction the group covers all 64 banks exactly once, for any sample position.
 //   far        = an in-range sample with a corner outside its window takes raw buffer loads (invalid corners at an
@@ -32,6 +32,7 @@
 // All geometry comes from the int64 shape tensors on the device; the host only knows S, so the grid has
 // ceil(S / 128) workgroups per (image, head) -- at least the number of tiles of any pyramid whose level 0 holds
 // <= ~3/4 of the pixels -- and a workgroup walks tiles g, g + G, ... (one tile, or none, at the R50 shapes).
+#include <cstdlib>
 #include <type_traits>
 
 #include "msda_common.hpp"
@@ -52,7 +53,9 @@ constexpr int kSlots = kBase[4];
 constexpr int kZeroOff = kSlots * 128;                          // all-zero region: target of dead / far samples
 constexpr int kZeroBytes = kWW[0] * 128 + 256;                  // a bottom-row read lands at most one level-0 row further
 struct Meta {
-  int sum[4][4];                                                // per level: sum x0, sum y0, count, unused
+  int sum[2][4][4];                                             // [item parity] per level: sum x0, sum y0, count, unused
+  int geo[4][4];                                                // per level: first column / row and width of the tile's queries
+  int org[4][4];                                                // per level: window origin x, y; last near column / row
 };
 constexpr int kMetaOff = kZeroOff + kZeroBytes;
 constexpr int kLdsBytes = kMetaOff + ((sizeof(Meta) + 15) / 16) * 16;
@@ -68,7 +71,7 @@ __device__ unsigned long long g_win_prof[kProfBlocks * kProfSlots];
 #define WIN_STAMP(i)                                                                                         \
   do {                                                                                                       \
     if (threadIdx.x == 0 && tile == g) {                                                                     \
-      const unsigned blk_ = blockIdx.y * gridDim.x + blockIdx.x;                                             \
+      const unsigned blk_ = blockIdx.x;                                             \
       if (blk_ < (unsigned)kProfBlocks) g_win_prof[blk_ * kProfSlots + (i)] = __builtin_amdgcn_s_memrealtime(); \
     }                                                                                                        \
   } while (0)
@@ -76,48 +79,45 @@ __device__ unsigned long long g_win_prof[kProfBlocks * kProfSlots];
 #define WIN_STAMP(i) do { } while (0)
 #endif
 
+typedef float v2f __attribute__((ext_vector_type(2)));        // packed fp32 math: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32
+
 template <int SRC>
 __device__ __forceinline__ uint32_t qb(uint32_t v) {   // value held by lane SRC of this lane's quad
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, SRC * 0x55, 0xF, 0xF, true);
 }
 template <int SRC>
 __device__ __forceinline__ float qbf(float v) { return __uint_as_float(qb<SRC>(__float_as_uint(v))); }
-// acc += (w as held by lane SRC of the quad) * d: the broadcast rides on the FMA's DPP operand (the compiler folds DPP
-// into adds but not into v_fmac, so this one is spelled out)
-template <int SRC>
-__device__ __forceinline__ void fma_qb(float& acc, float w, float d) {
-  asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[%3,%3,%3,%3] row_mask:0xf bank_mask:0xf bound_ctrl:1"
-               : "+v"(acc) : "v"(w), "v"(d), "n"(SRC));
-}
+template <int CTRL>
+__device__ __forceinline__ int dppi(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
 
-// One prepared sample in the preparing lane's registers.
-//   near: w = (first-top, second-top, first-bottom, second-bottom) corner weights, a0 / a1 = LDS byte address of the
-//         first / second pixel of the top row ("first" = the pixel whose slot parity this quad reads first)
-//   far : w = (TL, TR, BL, BR) weights, a0 = byte offset of the top-left pixel in `value` (image-relative, modular),
-//         a1 = corner validity bits
-//   dead: w = 0, a0 / a1 = the zero region
+// One prepared NEAR sample in the preparing lane's registers: corner weights (first-top, second-top), (first-bottom,
+// second-bottom) and the LDS byte addresses of the first / second pixel of the top row -- "first" is the pixel whose
+// slot parity this quad reads first.  Dead and far samples carry zero weights and point at the zero region.
 struct Smp {
-  float w[4];
-  uint32_t a0, a1;
+  v2f wT, wB;
+  uint32_t aF, aS;
 };
 
 }  // namespace
 
+// The kernel is VALU-issue bound (a wave64 VALU instruction occupies its SIMD for 4 clocks; profiles/): every
+// per-sample instruction below is counted -- hence packed fp32 math wherever two lanes of work sit side by side --
+// and short of registers (128 at 4 waves per SIMD): per-lane level constants are re-derived from the lane id in
+// every round, tile geometry and window origins are parked in LDS between rounds.
+template <int DMA_AUX>   // cache policy bits of the window DMA (0 = default, 2 = non-temporal)
 __global__ void __launch_bounds__(kT, 4)
 msda_fwd_win(const float* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
-             const float* __restrict__ loc, const float* __restrict__ attn, Dims d, int G, float* __restrict__ out) {
+             const float* __restrict__ loc, const float* __restrict__ attn, Dims d, float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Meta& mt = *reinterpret_cast<Meta*>(smem + kMetaOff);
   const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int k = lane & 3, pq = lane >> 2;                 // lane of the quad = level it prepares; quad of the wave
-  const int cls_a = (pq >> 1) & 1, cls_e = (pq >> 2) & 1; // bank class of the quad: half read first, parity read first
-  const uint32_t c0 = (uint32_t)(32 * k + 16 * cls_a);    // this lane's first 16 bytes inside a pixel (second: ^ 16)
-  const int M = d.M, b = blockIdx.y;
-  const int m = blockIdx.x % M, g = blockIdx.x / M;
+  const int pq = lane >> 2;                                // quad of the wave
+  const int M = d.M;
+  const int m = blockIdx.x % M, kk = blockIdx.x / M, K = gridDim.x / M;   // workgroup kk of K on head m
 
-  // ---- launch constants straight from the shape tensors (uniform addresses: scalar loads, no LDS table, no barrier) --
+  // ---- launch constants straight from the shape tensors (uniform addresses: scalar loads, no LDS table) ------------
   int lvH[4], lvW[4], lvS[4];
 #pragma unroll
   for (int l = 0; l < 4; ++l) {
@@ -126,124 +126,130 @@ msda_fwd_win(const float* __restrict__ value, const int64_t* __restrict__ shapes
     lvS[l] = (int)lsi[l];
   }
   const int TY = (lvH[0] + kTH - 1) / kTH, TX = (lvW[0] + kTW - 1) / kTW;
-  const int ntiles = TY * TX;
-  if (g >= ntiles) return;                                 // over-provisioned part of the grid
-  // the all-zero region, the placement sums of the first tile
+  const int ntiles = TY * TX, nitems = d.N * ntiles;       // work items of this head: (image, tile), image-major
+  if (kk >= nitems) return;                                // over-provisioned part of the grid
+  // the all-zero region, the placement sums (two sets: consecutive items alternate)
   for (int o = tid * 16; o < kZeroBytes; o += kT * 16) *reinterpret_cast<f32x4*>(smem + kZeroOff + o) = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (tid < 16) (&mt.sum[0][0])[tid] = 0;
+  if (tid < 32) (&mt.sum[0][0][0])[tid] = 0;
   __syncthreads();                                         // the sums are zero before any wave adds to them
 
-  // this lane's own level (it prepares level k)
-  const int myH = k == 0 ? lvH[0] : k == 1 ? lvH[1] : k == 2 ? lvH[2] : lvH[3];
-  const int myW = k == 0 ? lvW[0] : k == 1 ? lvW[1] : k == 2 ? lvW[2] : lvW[3];
-  const int myS = k == 0 ? lvS[0] : k == 1 ? lvS[1] : k == 2 ? lvS[2] : lvS[3];
-  const int myWH = k == 0 ? kWH[0] : k == 1 ? kWH[1] : k == 2 ? kWH[2] : kWH[3];
-  const int myWW = k == 0 ? kWW[0] : k == 1 ? kWW[1] : k == 2 ? kWW[2] : kWW[3];
-  const uint32_t myWin = smem_base + 128u * (uint32_t)(k == 0 ? kBase[0] : k == 1 ? kBase[1] : k == 2 ? kBase[2] : kBase[3]);
-  const uint32_t zero_first = smem_base + kZeroOff + 128u * (uint32_t)cls_e;        // parity cls_e
-  const uint32_t zero_second = smem_base + kZeroOff + 128u * (uint32_t)(cls_e ^ 1);
-  // tile -> query rectangle of level k along one axis: pixels [f(t), f(t + 1)) with f(t) = ceil(t * T * n / n0 - 1/2),
-  // i.e. the pixels whose centre falls into the tile.  Evaluated in float: any monotone f with f(0) = 0 gives an exact
-  // partition as long as every workgroup evaluates the same expression, which is all that correctness needs.
-  const float fxs = (float)(kTW * myW) / (float)lvW[0], fys = (float)(kTH * myH) / (float)lvH[0];
-
   const uint32_t pixB = (uint32_t)M * 128u;
-  const uint32_t myRowG = (uint32_t)myW * pixB;
-  const __amdgpu_buffer_rsrc_t vsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(value) + (int64_t)b * d.S * M * 32, 0, (int)((uint32_t)d.S * pixB), 0x00020000);
   const uint32_t hoff = (uint32_t)m * 128u;
-  const int64_t pair_img = (int64_t)b * d.Lq * M;           // first (query, head) pair of image b
 
-  for (int tile = g; tile < ntiles; tile += G) {
+  for (int item = kk, it = 0; item < nitems; item += K, ++it) {
+#ifdef MSDA_WIN_PROF
+    const int tile = it, g = 0;                             // WIN_STAMP records the first item of a workgroup
+#endif
     WIN_STAMP(0);
-    const int ty = (int)(((float)tile + 0.5f) / (float)TX), tx = tile - ty * TX;
-    // ---- tile geometry: lane k owns level k's query rectangle, the quad shares it by DPP ---------------------------
-    int gxs, gys, gnx, gny;
-    {
-      const int xs = min(max((int)ceilf((float)tx * fxs - 0.5f), 0), myW);
-      const int xe = tx == TX - 1 ? myW : min(max((int)ceilf((float)(tx + 1) * fxs - 0.5f), xs), myW);
-      const int ys = min(max((int)ceilf((float)ty * fys - 0.5f), 0), myH);
-      const int ye = ty == TY - 1 ? myH : min(max((int)ceilf((float)(ty + 1) * fys - 0.5f), ys), myH);
-      gxs = xs; gys = ys; gnx = xe - xs; gny = ye - ys;
-    }
-    const int cnt = gnx * gny;
-    const int c1 = (int)qb<0>((uint32_t)cnt), c2 = c1 + (int)qb<1>((uint32_t)cnt), c3 = c2 + (int)qb<2>((uint32_t)cnt);
-    const int nq = __builtin_amdgcn_readfirstlane(c3 + (int)qb<3>((uint32_t)cnt));   // queries of this tile
-    WIN_STAMP(1);
-
-    // a round = the next 128 queries of the tile, one per quad
-    auto query_of = [&](int qi, bool live) __attribute__((always_inline)) -> int64_t {
-      const int ql = live ? (qi >= c1 ? 1 : 0) + (qi >= c2 ? 1 : 0) + (qi >= c3 ? 1 : 0) : 0;
-      const int j = qi - (ql == 0 ? 0 : ql == 1 ? c1 : ql == 2 ? c2 : c3);
-      const int nx = ql == 0 ? (int)qb<0>((uint32_t)gnx) : ql == 1 ? (int)qb<1>((uint32_t)gnx) : ql == 2 ? (int)qb<2>((uint32_t)gnx) : (int)qb<3>((uint32_t)gnx);
-      const int xs = ql == 0 ? (int)qb<0>((uint32_t)gxs) : ql == 1 ? (int)qb<1>((uint32_t)gxs) : ql == 2 ? (int)qb<2>((uint32_t)gxs) : (int)qb<3>((uint32_t)gxs);
-      const int ys = ql == 0 ? (int)qb<0>((uint32_t)gys) : ql == 1 ? (int)qb<1>((uint32_t)gys) : ql == 2 ? (int)qb<2>((uint32_t)gys) : (int)qb<3>((uint32_t)gys);
-      const int Wq = ql == 0 ? lvW[0] : ql == 1 ? lvW[1] : ql == 2 ? lvW[2] : lvW[3];
-      const int Sq = ql == 0 ? lvS[0] : ql == 1 ? lvS[1] : ql == 2 ? lvS[2] : lvS[3];
-      const int yy = (int)(((float)j + 0.5f) / (float)max(nx, 1));
-      const int q = Sq + (ys + yy) * Wq + xs + (j - yy * nx);
-      return pair_img + (int64_t)(live ? q : 0) * M + m;
-    };
-    // lane k: the four points of level k -- 32 B of locations, 16 B of weights
-    f32x4 lcA, lcB, at;
-    auto fetch = [&](int64_t pair, bool live) __attribute__((always_inline)) {
+    if (it > 0) __syncthreads();                            // (odd pyramids / persistent grids) everybody left the previous item
+    const int b = (int)(((float)item + 0.5f) / (float)ntiles);
+    const int64_t pair_img = (int64_t)b * d.Lq * M;         // first (query, head) pair of this item's image
+    const __amdgpu_buffer_rsrc_t vsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(value) + (int64_t)b * d.S * M * 32, 0, (int)((uint32_t)d.S * pixB), 0x00020000);
+    int (*const sums)[4] = mt.sum[it & 1];
+    int nrest;                                              // queries of levels 1..3 of this item, and where they start
+    int e1, e2;
+    f32x4 lcA, lcB, at;                                     // lane k: the four points of level k -- 32 B + 16 B
+    int64_t pair;
+    bool live;
+    auto fetch = [&](int kq) __attribute__((always_inline)) {
       lcA = lcB = at = f32x4{0.f, 0.f, 0.f, 0.f};
       if (live) {
-        const f32x4* lp = reinterpret_cast<const f32x4*>(loc + pair * 32 + 8 * k);
+        const f32x4* lp = reinterpret_cast<const f32x4*>(loc + pair * 32 + 8 * kq);
         lcA = __builtin_nontemporal_load(lp);
         lcB = __builtin_nontemporal_load(lp + 1);
-        at = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(attn + pair * 16 + 4 * k));
+        at = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(attn + pair * 16 + 4 * kq));
       }
     };
-    int qi = wv * 16 + pq;
-    bool live = qi < nq;
-    int64_t pair = query_of(qi, live);
-    fetch(pair, live);
-    int myOx = 0, myOy = 0;                                    // window origin of level k, known after the first round
+    {
+      // ---- tile geometry: lane k owns level k's query rectangle, the quad shares it by DPP, LDS keeps it ---------
+      // level-k pixels [f(t), f(t + 1)) with f(t) = ceil(t * T * n / n0 - 1/2) are the ones whose centre falls into
+      // tile t.  Evaluated in float: any monotone f with f(0) = 0 gives an exact partition as long as every workgroup
+      // evaluates the same expression, which is all that correctness needs.
+      const int kq = lane & 3;
+      const int gW = kq == 0 ? lvW[0] : kq == 1 ? lvW[1] : kq == 2 ? lvW[2] : lvW[3];
+      const int gH = kq == 0 ? lvH[0] : kq == 1 ? lvH[1] : kq == 2 ? lvH[2] : lvH[3];
+      const float fxs = (float)(kTW * gW) / (float)lvW[0], fys = (float)(kTH * gH) / (float)lvH[0];
+      const int tile_ = item - b * ntiles;
+      const int ty = (int)(((float)tile_ + 0.5f) / (float)TX), tx = tile_ - ty * TX;
+      const int xs = min(max((int)ceilf((float)tx * fxs - 0.5f), 0), gW);
+      const int xe = tx == TX - 1 ? gW : min(max((int)ceilf((float)(tx + 1) * fxs - 0.5f), xs), gW);
+      const int ys = min(max((int)ceilf((float)ty * fys - 0.5f), 0), gH);
+      const int ye = ty == TY - 1 ? gH : min(max((int)ceilf((float)(ty + 1) * fys - 0.5f), ys), gH);
+      const int nx = xe - xs, cnt = nx * (ye - ys);
+      if (tid < 4) *reinterpret_cast<int4*>(&mt.geo[kq][0]) = make_int4(xs, ys, nx, 0);   // read after the placement barrier
+      e1 = __builtin_amdgcn_readfirstlane((int)qb<1>((uint32_t)cnt));
+      e2 = e1 + __builtin_amdgcn_readfirstlane((int)qb<2>((uint32_t)cnt));
+      nrest = e2 + __builtin_amdgcn_readfirstlane((int)qb<3>((uint32_t)cnt));
+      // round 0 = the level-0 queries of the tile, wave = tile row, quad = tile column (no division)
+      live = pq < (int)qb<0>((uint32_t)nx) && wv < (int)qb<0>((uint32_t)(ye - ys));
+      const int q = lvS[0] + ((int)qb<0>((uint32_t)ys) + wv) * lvW[0] + (int)qb<0>((uint32_t)xs) + pq;
+      pair = pair_img + (int64_t)(live ? q : 0) * M + m;
+      fetch(kq);
+    }
+    WIN_STAMP(1);
+    // this wave's rounds: a wave without a live quad has nothing to do after round 0 (no barrier in the later rounds)
+    const int nrounds = 1 + (nrest > wv * 16 ? (nrest - wv * 16 + kQuads - 1) / kQuads : 0);
 
-    for (int q0 = 0; q0 < nq; q0 += kQuads) {
-      // sample coordinates (the reference's arithmetic, cuh:282-288 and :38-46)
-      float sx[4], sy[4], sa[4];
+    for (int rnd = 0; rnd < nrounds; ++rnd) {
+      // ---- per-lane constants of this lane's level, re-derived every round (see the kernel header) ----------------
+      int k = lane & 3;
+      asm volatile("" : "+v"(k));                            // opaque: nothing below is hoisted out of the round loop
+      const int cls_a = (lane >> 3) & 1, cls_e = (lane >> 4) & 1;   // bank class of the quad: half read first, parity read first
+      // this lane's channels: the 16-byte pieces k and k + 4 of a pixel, i.e. a quad reads / writes 64 contiguous bytes
+      // per instruction; c0 = the piece read first, c0 ^ 64 the other
+      const uint32_t c0 = (uint32_t)(16 * k + 64 * cls_a);
+      const int myH = k == 0 ? lvH[0] : k == 1 ? lvH[1] : k == 2 ? lvH[2] : lvH[3];
+      const int myW = k == 0 ? lvW[0] : k == 1 ? lvW[1] : k == 2 ? lvW[2] : lvW[3];
+      const int myWH = k == 0 ? kWH[0] : k == 1 ? kWH[1] : k == 2 ? kWH[2] : kWH[3];
+      const int myWW = k == 0 ? kWW[0] : k == 1 ? kWW[1] : k == 2 ? kWW[2] : kWW[3];
+      const v2f fWH = {(float)myW, (float)myH};
+
+      // ---- sample coordinates (the reference's arithmetic, cuh:282-288 and :38-46) ----------------------------------
+      v2f xy[4], fl[4];
+      float sa[4];
       bool inr[4];
       int x0[4], y0[4];
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
-        const float lx = p == 0 ? lcA[0] : p == 1 ? lcA[2] : p == 2 ? lcB[0] : lcB[2];
-        const float ly = p == 0 ? lcA[1] : p == 1 ? lcA[3] : p == 2 ? lcB[1] : lcB[3];
+        const v2f l2 = p == 0 ? v2f{lcA[0], lcA[1]} : p == 1 ? v2f{lcA[2], lcA[3]} : p == 2 ? v2f{lcB[0], lcB[1]} : v2f{lcB[2], lcB[3]};
         sa[p] = at[p];
-        sx[p] = lx * (float)myW - 0.5f;
-        sy[p] = ly * (float)myH - 0.5f;
-        inr[p] = live && (sy[p] > -1.f) && (sx[p] > -1.f) && (sy[p] < (float)myH) && (sx[p] < (float)myW);
-        x0[p] = inr[p] ? (int)floorf(sx[p]) : 0;
-        y0[p] = inr[p] ? (int)floorf(sy[p]) : 0;
+        xy[p] = __builtin_elementwise_fma(l2, fWH, v2f{-0.5f, -0.5f});
+        fl[p] = v2f{floorf(xy[p].x), floorf(xy[p].y)};
+        inr[p] = live && (xy[p].y > -1.f) && (xy[p].x > -1.f) && (xy[p].y < fWH.y) && (xy[p].x < fWH.x);
+        x0[p] = inr[p] ? (int)fl[p].x : 0;
+        y0[p] = inr[p] ? (int)fl[p].y : 0;
       }
 
-      if (q0 == 0) {
+      int myOx, myOy;                                          // window origin of level k
+      uint32_t cxmax, rymax;                                   // largest window column / row a top-left corner may take
+      if (rnd == 0) {
         WIN_STAMP(2);                                          // loc / attn have arrived, sample coordinates done
         // ---- window placement: mean top-left corner of this tile's in-range samples, per level ---------------------
         int ax = 0, ay = 0, an = 0;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-          ax += inr[p] ? x0[p] : 0;
-          ay += inr[p] ? y0[p] : 0;
+          ax += x0[p];                                         // 0 when out of range
+          ay += y0[p];
           an += inr[p] ? 1 : 0;
         }
-#pragma unroll
-        for (int o = 4; o < 64; o <<= 1) {                   // over the 16 quads of the wave (same k)
-          ax += __shfl_xor(ax, o, 64);
-          ay += __shfl_xor(ay, o, 64);
-          an += __shfl_xor(an, o, 64);
-        }
-        if (pq == 0 && an > 0) {
-          atomicAdd(&mt.sum[k][0], ax);
-          atomicAdd(&mt.sum[k][1], ay);
-          atomicAdd(&mt.sum[k][2], an);
+        // over the 16 quads of the wave (lanes with the same k): row_shr 4 / 8 inside a row of 16, then rows
+        ax += dppi<0x114>(ax); ay += dppi<0x114>(ay); an += dppi<0x114>(an);
+        ax += dppi<0x118>(ax); ay += dppi<0x118>(ay); an += dppi<0x118>(an);   // lanes 12..15 of a row: the row's total
+        ax += __shfl_xor(ax, 16, 64); ay += __shfl_xor(ay, 16, 64); an += __shfl_xor(an, 16, 64);
+        ax += __shfl_xor(ax, 32, 64); ay += __shfl_xor(ay, 32, 64); an += __shfl_xor(an, 32, 64);
+        if (pq == 3 && an > 0) {
+          atomicAdd(&sums[k][0], ax);
+          atomicAdd(&sums[k][1], ay);
+          atomicAdd(&sums[k][2], an);
         }
         __syncthreads();
         WIN_STAMP(3);
         {
-          const int4 sm = *reinterpret_cast<const int4*>(&mt.sum[k][0]);
-          myOx = gxs - 3; myOy = gys - 3;
+          const int4 sm = *reinterpret_cast<const int4*>(&sums[k][0]);
+          const int4 ge = *reinterpret_cast<const int4*>(&mt.geo[k][0]);
+          if (tid < 16) (&mt.sum[(it & 1) ^ 1][0][0])[tid] = 0;   // the next item's sums: nobody reads or adds to them now
+          myOx = ge.x - 3; myOy = ge.y - 3;
           if (sm.z > 0) {   // v_rcp_f32: every lane of the workgroup evaluates the same expression on the same sums
             const float inv = __builtin_amdgcn_rcpf((float)sm.z);
             myOx = (int)floorf((float)sm.x * inv + 0.5f) - (myWW - 2) / 2;
@@ -251,6 +257,10 @@ msda_fwd_win(const float* __restrict__ value, const int64_t* __restrict__ shapes
           }
           myOx = max(-1, min(myOx, myW + 1 - myWW));
           myOy = max(-1, min(myOy, myH + 1 - myWH));
+          // a level smaller than its window: top-left corners past the last in-range one are not "near"
+          cxmax = (uint32_t)(min(myOx + myWW - 2, myW - 1) - myOx);
+          rymax = (uint32_t)(min(myOy + myWH - 2, myH - 1) - myOy);
+          if (tid < 4) *reinterpret_cast<int4*>(&mt.org[k][0]) = make_int4(myOx, myOy, (int)cxmax, (int)rymax);   // for the later rounds
         }
         // ---- stage the four windows: LDS-DMA, one instruction = 8 consecutive slots (1 KB) of ONE level per wave -------
         {
@@ -261,109 +271,125 @@ msda_fwd_win(const float* __restrict__ value, const int64_t* __restrict__ shapes
           ogx[3] = __builtin_amdgcn_readfirstlane((int)qb<3>((uint32_t)myOx)); ogy[3] = __builtin_amdgcn_readfirstlane((int)qb<3>((uint32_t)myOy));
           const uint32_t chunk = (uint32_t)(lane & 7) * 16u;
           const int sub = lane >> 3;
+          int cl = -1, r = 0, c = 0;                            // level of the previous chunk, this lane's window row / column
           for (int i = wv; i < kSlots / 8; i += kWaves) {        // i, and with it the level, is wave-uniform
             const int sl = (i >= kBase[1] / 8 ? 1 : 0) + (i >= kBase[2] / 8 ? 1 : 0) + (i >= kBase[3] / 8 ? 1 : 0);
-            const int rel = 8 * i + sub - (sl == 0 ? kBase[0] : sl == 1 ? kBase[1] : sl == 2 ? kBase[2] : kBase[3]);
             const int ww = sl == 0 ? kWW[0] : sl == 1 ? kWW[1] : sl == 2 ? kWW[2] : kWW[3];
-            const int r = (int)(((float)rel + 0.5f) * (sl == 0 ? 1.f / kWW[0] : sl == 1 ? 1.f / kWW[1] : sl == 2 ? 1.f / kWW[2] : 1.f / kWW[3]));
-            const int y = (sl == 0 ? ogy[0] : sl == 1 ? ogy[1] : sl == 2 ? ogy[2] : ogy[3]) + r;
-            const int x = (sl == 0 ? ogx[0] : sl == 1 ? ogx[1] : sl == 2 ? ogx[2] : ogx[3]) + rel - r * ww;
+            if (sl != cl) {                                      // first chunk of a level for this wave (uniform branch)
+              const int rel = 8 * i + sub - (sl == 0 ? kBase[0] : sl == 1 ? kBase[1] : sl == 2 ? kBase[2] : kBase[3]);
+              r = (int)(((float)rel + 0.5f) * (sl == 0 ? 1.f / kWW[0] : sl == 1 ? 1.f / kWW[1] : sl == 2 ? 1.f / kWW[2] : 1.f / kWW[3]));
+              c = rel - r * ww;
+              cl = sl;
+            } else {                                             // 8 waves x 8 slots further in the same window
+              c += 64 % ww; r += 64 / ww;
+              if (c >= ww) { c -= ww; r += 1; }
+            }
             const int Hs = sl == 0 ? lvH[0] : sl == 1 ? lvH[1] : sl == 2 ? lvH[2] : lvH[3];
             const int Ws = sl == 0 ? lvW[0] : sl == 1 ? lvW[1] : sl == 2 ? lvW[2] : lvW[3];
             const int Ss = sl == 0 ? lvS[0] : sl == 1 ? lvS[1] : sl == 2 ? lvS[2] : lvS[3];
-            const bool inside = (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws;   // also false for the pad slots' rows
-            const uint32_t off = inside ? (uint32_t)(Ss + y * Ws + x) * pixB + chunk : kOobOffset;
+            const int y = (sl == 0 ? ogy[0] : sl == 1 ? ogy[1] : sl == 2 ? ogy[2] : ogy[3]) + r;
+            const int x = (sl == 0 ? ogx[0] : sl == 1 ? ogx[1] : sl == 2 ? ogx[2] : ogx[3]) + c;
+            const bool inside = (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws;
+            const uint32_t pix = (uint32_t)__mul24(__mul24(y, Ws) + x + Ss, M);   // < 2^24 by win_forward_ok
+            const uint32_t off = inside ? (pix << 7) + chunk : kOobOffset;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(vsrc, (__attribute__((address_space(3))) void*)(smem + i * 1024), 16,
-                                                     off, hoff, 0, 0);
+                                                     off, hoff, 0, DMA_AUX);
           }
         }
         WIN_STAMP(4);                                          // window DMA issued
+      } else {
+        const int4 og = *reinterpret_cast<const int4*>(&mt.org[k][0]);
+        myOx = og.x; myOy = og.y; cxmax = (uint32_t)og.z; rymax = (uint32_t)og.w;
       }
 
       // ---- prepare this lane's four samples ---------------------------------------------------------------------------
       Smp smp[4];
       uint32_t farmask = 0;
+      {
+        const uint32_t myWin = smem_base + 128u * (uint32_t)(k == 0 ? kBase[0] : k == 1 ? kBase[1] : k == 2 ? kBase[2] : kBase[3]);
+        const uint32_t zero_first = smem_base + kZeroOff + 128u * (uint32_t)cls_e;        // parity cls_e
+        const uint32_t zero_second = smem_base + kZeroOff + 128u * (uint32_t)(cls_e ^ 1);
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const float a = sa[p];
-        const float fx = sx[p] - floorf(sx[p]), fy = sy[p] - floorf(sy[p]);
-        const float wt = (1.f - fy) * a, wb = fy * a;
-        const float wTL = wt * (1.f - fx), wTR = wt * fx, wBL = wb * (1.f - fx), wBR = wb * fx;
-        const int cx = x0[p] - myOx, ry = y0[p] - myOy;
-        const bool near = inr[p] && (unsigned)cx <= (unsigned)(myWW - 2) && (unsigned)ry <= (unsigned)(myWH - 2);
-        const bool far = inr[p] && !near;
-        const bool swap = ((cx & 1) != cls_e);
-        const uint32_t tl = myWin + (uint32_t)(ry * myWW + cx) * 128u;
-        const bool t_ok = y0[p] >= 0, b_ok = y0[p] + 1 <= myH - 1, l_ok = x0[p] >= 0, r_ok = x0[p] + 1 <= myW - 1;
-        const uint32_t bits = (t_ok && l_ok ? 1u : 0u) | (t_ok && r_ok ? 2u : 0u) | (b_ok && l_ok ? 4u : 0u) | (b_ok && r_ok ? 8u : 0u);
-        const uint32_t goff = (uint32_t)(myS + y0[p] * myW + x0[p]) * pixB;
-        smp[p].w[0] = near ? (swap ? wTR : wTL) : far ? wTL : 0.f;
-        smp[p].w[1] = near ? (swap ? wTL : wTR) : far ? wTR : 0.f;
-        smp[p].w[2] = near ? (swap ? wBR : wBL) : far ? wBL : 0.f;
-        smp[p].w[3] = near ? (swap ? wBL : wBR) : far ? wBR : 0.f;
-        smp[p].a0 = near ? (swap ? tl + 128u : tl) : far ? goff : zero_first;
-        smp[p].a1 = near ? (swap ? tl : tl + 128u) : far ? bits : zero_second;
-        farmask |= far ? (1u << p) : 0u;
+        for (int p = 0; p < 4; ++p) {
+          v2f fr = xy[p] - fl[p];                                // (fx, fy); inf - inf / NaN for poisoned locations ...
+          fr.x = fmaxf(fr.x, 0.f); fr.y = fmaxf(fr.y, 0.f);      // ... which must not turn the zero weights of dead samples into NaN
+          const v2f om = v2f{1.f, 1.f} - fr;                     // (1 - fx, 1 - fy)
+          const int cx = x0[p] - myOx, ry = y0[p] - myOy;
+          const bool near = inr[p] && (uint32_t)cx <= cxmax && (uint32_t)ry <= rymax;
+          farmask |= (inr[p] && !near) ? (1u << p) : 0u;
+          const uint32_t sw = (uint32_t)(cx ^ cls_e) & 1u;       // 1: the right-hand pixel has this quad's first parity
+          const float an = near ? sa[p] : 0.f;                   // dead and far samples: all four weights 0
+          const v2f gx = sw ? v2f{fr.x, om.x} : v2f{om.x, fr.x}; // x factors of the (first, second) pixel
+          const v2f wtb = v2f{om.y, fr.y} * an;                  // (top, bottom) row weight x attention weight
+          smp[p].wT = gx * wtb.x;
+          smp[p].wB = gx * wtb.y;
+          const uint32_t tl = myWin + (uint32_t)(__mul24(ry, myWW) + cx) * 128u;
+          smp[p].aF = near ? tl + (sw << 7) : zero_first;
+          smp[p].aS = near ? tl + 128u - (sw << 7) : zero_second;
+        }
       }
 
-      f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};   // channels at c0 and at c0 ^ 16
-      if (q0 == 0) WIN_STAMP(5);                               // samples prepared
+      f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};   // channels at c0 and at c0 ^ 64
+      if (rnd == 0) WIN_STAMP(5);                              // samples prepared
 
-      // ---- far samples: raw buffer loads, one far sample per quad and step (overlaps the window DMA in round 0) ----------
+      // ---- far samples: raw buffer loads, one far sample per quad and step (behind the window DMA in round 0: vmcnt is
+      // in order, so this pass also sits out most of the DMA's latency; issuing its loads ahead of an unrolled,
+      // fixed-count DMA was tried and cost > 100 spilled registers) ---------------------------------------------------------
       {
         uint32_t fm = farmask << (4 * k);                      // the pair's 16 samples: bit 4 * level + point
-        fm |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)fm, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-        fm |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)fm, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
-        const uint32_t gfirst = 32u * (uint32_t)k + 16u * (uint32_t)cls_a;
-        while (__ballot(fm != 0u)) {
+        fm |= (uint32_t)dppi<0xB1>((int)fm);                   // quad_perm [1,0,3,2]
+        fm |= (uint32_t)dppi<0x4E>((int)fm);                   // quad_perm [2,3,0,1]
+        struct Far { f32x4 d1a, d1b, d2a, d2b, d3a, d3b, d4a, d4b; float w1, w2, w3, w4; };
+        auto far_issue = [&](Far& f) __attribute__((always_inline)) {
           const bool has = fm != 0u;
           const int idx = has ? __builtin_ctz(fm) : 0;
           fm &= fm - 1u;
-          const int ps = idx & 3;
-          const int src = ((lane & ~3) | (idx >> 2)) << 2;     // byte address of the preparing lane for ds_bpermute
-          // the preparing lane's sample `ps`: every lane selects its own candidate, the quad pulls the right one
-          const float cw0 = ps == 0 ? smp[0].w[0] : ps == 1 ? smp[1].w[0] : ps == 2 ? smp[2].w[0] : smp[3].w[0];
-          const float cw1 = ps == 0 ? smp[0].w[1] : ps == 1 ? smp[1].w[1] : ps == 2 ? smp[2].w[1] : smp[3].w[1];
-          const float cw2 = ps == 0 ? smp[0].w[2] : ps == 1 ? smp[1].w[2] : ps == 2 ? smp[2].w[2] : smp[3].w[2];
-          const float cw3 = ps == 0 ? smp[0].w[3] : ps == 1 ? smp[1].w[3] : ps == 2 ? smp[2].w[3] : smp[3].w[3];
-          const uint32_t ca0 = ps == 0 ? smp[0].a0 : ps == 1 ? smp[1].a0 : ps == 2 ? smp[2].a0 : smp[3].a0;
-          const uint32_t ca1 = ps == 0 ? smp[0].a1 : ps == 1 ? smp[1].a1 : ps == 2 ? smp[2].a1 : smp[3].a1;
-          const uint32_t off = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)ca0);
-          const uint32_t bits = has ? (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)ca1) : 0u;
-          const uint32_t rowG = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)myRowG);
-          const float w1 = has ? __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)__float_as_uint(cw0))) : 0.f;
-          const float w2 = has ? __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)__float_as_uint(cw1))) : 0.f;
-          const float w3 = has ? __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)__float_as_uint(cw2))) : 0.f;
-          const float w4 = has ? __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)__float_as_uint(cw3))) : 0.f;
-          const uint32_t o1 = (bits & 1u) ? off + gfirst : kOobOffset;
-          const uint32_t o2 = (bits & 2u) ? off + pixB + gfirst : kOobOffset;
-          const uint32_t o3 = (bits & 4u) ? off + rowG + gfirst : kOobOffset;
-          const uint32_t o4 = (bits & 8u) ? off + rowG + pixB + gfirst : kOobOffset;
-          const f32x4 d1a = buffer_load_f32x4(vsrc, o1, hoff), d1b = buffer_load_f32x4(vsrc, o1 ^ 16u, hoff);
-          const f32x4 d2a = buffer_load_f32x4(vsrc, o2, hoff), d2b = buffer_load_f32x4(vsrc, o2 ^ 16u, hoff);
-          const f32x4 d3a = buffer_load_f32x4(vsrc, o3, hoff), d3b = buffer_load_f32x4(vsrc, o3 ^ 16u, hoff);
-          const f32x4 d4a = buffer_load_f32x4(vsrc, o4, hoff), d4b = buffer_load_f32x4(vsrc, o4 ^ 16u, hoff);
+          const int ps = idx & 3, fl_ = idx >> 2;               // point and level of the far sample
+          const int src = ((lane & ~3) | fl_) << 2;            // byte address of the preparing lane for ds_bpermute
+          // the preparing lane's point `ps`: every lane selects its own candidate, the quad pulls the right one and
+          // redoes the (cheap) sample arithmetic -- far samples are a few per cent, their state is not kept around
+          const v2f cxy = ps == 0 ? xy[0] : ps == 1 ? xy[1] : ps == 2 ? xy[2] : xy[3];
+          const float ca = ps == 0 ? sa[0] : ps == 1 ? sa[1] : ps == 2 ? sa[2] : sa[3];
+          // quads without a far sample left run along with zero weights: their stand-in coordinates must be finite
+          const float fxv = has ? __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)__float_as_uint(cxy.x))) : 0.f;
+          const float fyv = has ? __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)__float_as_uint(cxy.y))) : 0.f;
+          const float fav = has ? __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)__float_as_uint(ca))) : 0.f;
+          const int fW = fl_ == 0 ? lvW[0] : fl_ == 1 ? lvW[1] : fl_ == 2 ? lvW[2] : lvW[3];
+          const int fH = fl_ == 0 ? lvH[0] : fl_ == 1 ? lvH[1] : fl_ == 2 ? lvH[2] : lvH[3];
+          const int fS = fl_ == 0 ? lvS[0] : fl_ == 1 ? lvS[1] : fl_ == 2 ? lvS[2] : lvS[3];
+          const uint32_t rowG = (uint32_t)fW * pixB;
+          const float xf = floorf(fxv), yf = floorf(fyv);
+          const float lw = fxv - xf, lh = fyv - yf;
+          const int fx0 = has ? (int)xf : 0, fy0 = has ? (int)yf : 0;
+          const bool t_ok = has && fy0 >= 0, b_ok = has && fy0 + 1 <= fH - 1, l_ok = fx0 >= 0, r_ok = fx0 + 1 <= fW - 1;
+          const float wt = (1.f - lh) * fav, wb = lh * fav;
+          f.w1 = wt * (1.f - lw); f.w2 = wt * lw; f.w3 = wb * (1.f - lw); f.w4 = wb * lw;
+          const uint32_t off = (uint32_t)(fS + fy0 * fW + fx0) * pixB + c0;
+          const uint32_t o1 = (t_ok && l_ok) ? off : kOobOffset;
+          const uint32_t o2 = (t_ok && r_ok) ? off + pixB : kOobOffset;
+          const uint32_t o3 = (b_ok && l_ok) ? off + rowG : kOobOffset;
+          const uint32_t o4 = (b_ok && r_ok) ? off + rowG + pixB : kOobOffset;
+          f.d1a = buffer_load_f32x4(vsrc, o1, hoff); f.d1b = buffer_load_f32x4(vsrc, o1 ^ 64u, hoff);
+          f.d2a = buffer_load_f32x4(vsrc, o2, hoff); f.d2b = buffer_load_f32x4(vsrc, o2 ^ 64u, hoff);
+          f.d3a = buffer_load_f32x4(vsrc, o3, hoff); f.d3b = buffer_load_f32x4(vsrc, o3 ^ 64u, hoff);
+          f.d4a = buffer_load_f32x4(vsrc, o4, hoff); f.d4b = buffer_load_f32x4(vsrc, o4 ^ 64u, hoff);
+        };
+        auto far_consume = [&](const Far& f) __attribute__((always_inline)) {
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            accA[c] = fmaf(w4, d4a[c], fmaf(w3, d3a[c], fmaf(w2, d2a[c], fmaf(w1, d1a[c], accA[c]))));
-            accB[c] = fmaf(w4, d4b[c], fmaf(w3, d3b[c], fmaf(w2, d2b[c], fmaf(w1, d1b[c], accB[c]))));
+            accA[c] = fmaf(f.w4, f.d4a[c], fmaf(f.w3, f.d3a[c], fmaf(f.w2, f.d2a[c], fmaf(f.w1, f.d1a[c], accA[c]))));
+            accB[c] = fmaf(f.w4, f.d4b[c], fmaf(f.w3, f.d3b[c], fmaf(f.w2, f.d2b[c], fmaf(f.w1, f.d1b[c], accB[c]))));
           }
           asm volatile("" : "+v"(accA), "+v"(accB));
-        }
-        // far samples are done: the LDS pass sees them as dead
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          const bool f = ((farmask >> p) & 1u) != 0u;
-          smp[p].w[0] = f ? 0.f : smp[p].w[0];
-          smp[p].w[1] = f ? 0.f : smp[p].w[1];
-          smp[p].w[2] = f ? 0.f : smp[p].w[2];
-          smp[p].w[3] = f ? 0.f : smp[p].w[3];
-          smp[p].a0 = f ? zero_first : smp[p].a0;
-          smp[p].a1 = f ? zero_second : smp[p].a1;
+        };
+        Far f0;
+        while (__ballot(fm != 0u)) {
+          far_issue(f0);
+          far_consume(f0);
         }
       }
 
-      if (q0 == 0) {
+      if (rnd == 0) {
         WIN_STAMP(6);                                          // far pass done
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of the windows has landed
         __syncthreads();                                     // ... and everybody else's
@@ -373,66 +399,80 @@ msda_fwd_win(const float* __restrict__ value, const int64_t* __restrict__ shapes
       // ---- the next round's locations and weights travel while this round reads the LDS ----------------------------------
       const int64_t cur_pair = pair;
       const bool cur_live = live;
-      if (q0 + kQuads < nq) {
-        qi += kQuads;
-        live = qi < nq;
-        pair = query_of(qi, live);
-        fetch(pair, live);
+      if (rnd + 1 < nrounds) {                                 // ri-th query of levels 1..3
+        const int ri = rnd * kQuads + wv * 16 + pq;
+        live = ri < nrest;
+        const int ql = 1 + (ri >= e1 ? 1 : 0) + (ri >= e2 ? 1 : 0);
+        const int j = ri - (ql == 1 ? 0 : ql == 2 ? e1 : e2);
+        const int4 ge = *reinterpret_cast<const int4*>(&mt.geo[ql][0]);     // xs, ys, nx of that level
+        const int Wq = ql == 1 ? lvW[1] : ql == 2 ? lvW[2] : lvW[3];
+        const int Sq = ql == 1 ? lvS[1] : ql == 2 ? lvS[2] : lvS[3];
+        const int yy = (int)(((float)j + 0.5f) / (float)max(ge.z, 1));
+        pair = pair_img + (int64_t)(live ? Sq + (ge.y + yy) * Wq + ge.x + (j - yy * ge.z) : 0) * M + m;
+        fetch(k);
       }
 
       // ---- near samples: 16 samples x 4 corners x 2 halves from the LDS windows ---------------------------------------
-      auto lds_step = [&](auto ltag, int p) __attribute__((always_inline)) {
+      v2f aA0 = {accA[0], accA[1]}, aA1 = {accA[2], accA[3]}, aB0 = {accB[0], accB[1]}, aB1 = {accB[2], accB[3]};
+      // Software pipeline in half-samples (a corner row = 4 reads + 8 packed FMAs): the top row of sample s + 1 is
+      // requested before the top row of sample s is consumed, and likewise the bottom rows -- three rows (48 registers)
+      // in flight at most, so one wave covers most of the LDS latency on its own (the other workgroup of the CU is
+      // usually waiting on memory); a full two-sample pipeline would not fit 128 registers.
+      struct Row { f32x4 Fa, Fb, Sa, Sb; };
+      struct Adr { lds4 pF, pF2, pS, pS2; };
+      auto fetch_top = [&](auto ltag, int p, Row& r, Adr& ad) __attribute__((always_inline)) {
         constexpr int LV = decltype(ltag)::value;
-        constexpr int kRow = kWW[LV] * 8;                     // one window row, in 16-byte units
-        const uint32_t aF = qb<LV>(smp[p].a0) + c0, aS = qb<LV>(smp[p].a1) + c0;
-        const lds4 pF = reinterpret_cast<lds4>((uintptr_t)aF), pF2 = reinterpret_cast<lds4>((uintptr_t)(aF ^ 16u));
-        const lds4 pS = reinterpret_cast<lds4>((uintptr_t)aS), pS2 = reinterpret_cast<lds4>((uintptr_t)(aS ^ 16u));
-        const f32x4 tFa = pF[0], tFb = pF2[0], tSa = pS[0], tSb = pS2[0];
-        const f32x4 bFa = pF[kRow], bFb = pF2[kRow], bSa = pS[kRow], bSb = pS2[kRow];
-        float accA_[4] = {accA[0], accA[1], accA[2], accA[3]}, accB_[4] = {accB[0], accB[1], accB[2], accB[3]};
-        // in load order, so that the waits on the LDS returns are progressive
-#pragma unroll
-        for (int c = 0; c < 4; ++c) fma_qb<LV>(accA_[c], smp[p].w[0], tFa[c]);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) fma_qb<LV>(accB_[c], smp[p].w[0], tFb[c]);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) fma_qb<LV>(accA_[c], smp[p].w[1], tSa[c]);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) fma_qb<LV>(accB_[c], smp[p].w[1], tSb[c]);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) fma_qb<LV>(accA_[c], smp[p].w[2], bFa[c]);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) fma_qb<LV>(accB_[c], smp[p].w[2], bFb[c]);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) fma_qb<LV>(accA_[c], smp[p].w[3], bSa[c]);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) fma_qb<LV>(accB_[c], smp[p].w[3], bSb[c]);
-        accA = f32x4{accA_[0], accA_[1], accA_[2], accA_[3]};
-        accB = f32x4{accB_[0], accB_[1], accB_[2], accB_[3]};
-        __builtin_amdgcn_sched_barrier(0);                    // one sample in flight per wave: 4 waves / SIMD hide the LDS
+        const uint32_t aF = qb<LV>(smp[p].aF) + c0, aS = qb<LV>(smp[p].aS) + c0;
+        ad.pF = reinterpret_cast<lds4>((uintptr_t)aF); ad.pF2 = reinterpret_cast<lds4>((uintptr_t)(aF ^ 64u));
+        ad.pS = reinterpret_cast<lds4>((uintptr_t)aS); ad.pS2 = reinterpret_cast<lds4>((uintptr_t)(aS ^ 64u));
+        r.Fa = ad.pF[0]; r.Fb = ad.pF2[0]; r.Sa = ad.pS[0]; r.Sb = ad.pS2[0];
+        __builtin_amdgcn_sched_barrier(0);
       };
-#pragma unroll
-      for (int p = 0; p < 4; ++p) lds_step(std::integral_constant<int, 0>{}, p);
-#pragma unroll
-      for (int p = 0; p < 4; ++p) lds_step(std::integral_constant<int, 1>{}, p);
-#pragma unroll
-      for (int p = 0; p < 4; ++p) lds_step(std::integral_constant<int, 2>{}, p);
-#pragma unroll
-      for (int p = 0; p < 4; ++p) lds_step(std::integral_constant<int, 3>{}, p);
+      auto fetch_bot = [&](auto ltag, Row& r, const Adr& ad) __attribute__((always_inline)) {
+        constexpr int kRow = kWW[decltype(ltag)::value] * 8;   // one window row, in 16-byte units
+        r.Fa = ad.pF[kRow]; r.Fb = ad.pF2[kRow]; r.Sa = ad.pS[kRow]; r.Sb = ad.pS2[kRow];
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      auto consume = [&](auto ltag, v2f wrow, const Row& r) __attribute__((always_inline)) {
+        constexpr int LV = decltype(ltag)::value;
+        const float wf = qbf<LV>(wrow.x), ws = qbf<LV>(wrow.y);
+        const v2f WF = {wf, wf}, WS = {ws, ws};
+        aA0 = __builtin_elementwise_fma(WF, v2f{r.Fa[0], r.Fa[1]}, aA0); aA1 = __builtin_elementwise_fma(WF, v2f{r.Fa[2], r.Fa[3]}, aA1);
+        aB0 = __builtin_elementwise_fma(WF, v2f{r.Fb[0], r.Fb[1]}, aB0); aB1 = __builtin_elementwise_fma(WF, v2f{r.Fb[2], r.Fb[3]}, aB1);
+        aA0 = __builtin_elementwise_fma(WS, v2f{r.Sa[0], r.Sa[1]}, aA0); aA1 = __builtin_elementwise_fma(WS, v2f{r.Sa[2], r.Sa[3]}, aA1);
+        aB0 = __builtin_elementwise_fma(WS, v2f{r.Sb[0], r.Sb[1]}, aB0); aB1 = __builtin_elementwise_fma(WS, v2f{r.Sb[2], r.Sb[3]}, aB1);
+        asm volatile("" : "+v"(aA0), "+v"(aA1), "+v"(aB0), "+v"(aB1));   // pins the FMAs here (IR-level sinking ignores sched_barrier)
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      {
+        Row t0, t1, b0, b1;
+        Adr ad;
+        using L0 = std::integral_constant<int, 0>; using L1 = std::integral_constant<int, 1>;
+        using L2 = std::integral_constant<int, 2>; using L3 = std::integral_constant<int, 3>;
+#define WIN_STEP(LC, PC, LN, PN, TC, BC, TN, BN)                                                \
+        fetch_top(LN{}, PN, TN, ad); consume(LC{}, smp[PC].wT, TC);                              \
+        fetch_bot(LN{}, BN, ad);     consume(LC{}, smp[PC].wB, BC);
+        fetch_top(L0{}, 0, t0, ad); fetch_bot(L0{}, b0, ad);
+        WIN_STEP(L0, 0, L0, 1, t0, b0, t1, b1) WIN_STEP(L0, 1, L0, 2, t1, b1, t0, b0)
+        WIN_STEP(L0, 2, L0, 3, t0, b0, t1, b1) WIN_STEP(L0, 3, L1, 0, t1, b1, t0, b0)
+        WIN_STEP(L1, 0, L1, 1, t0, b0, t1, b1) WIN_STEP(L1, 1, L1, 2, t1, b1, t0, b0)
+        WIN_STEP(L1, 2, L1, 3, t0, b0, t1, b1) WIN_STEP(L1, 3, L2, 0, t1, b1, t0, b0)
+        WIN_STEP(L2, 0, L2, 1, t0, b0, t1, b1) WIN_STEP(L2, 1, L2, 2, t1, b1, t0, b0)
+        WIN_STEP(L2, 2, L2, 3, t0, b0, t1, b1) WIN_STEP(L2, 3, L3, 0, t1, b1, t0, b0)
+        WIN_STEP(L3, 0, L3, 1, t0, b0, t1, b1) WIN_STEP(L3, 1, L3, 2, t1, b1, t0, b0)
+        WIN_STEP(L3, 2, L3, 3, t0, b0, t1, b1)
+        consume(L3{}, smp[3].wT, t1); consume(L3{}, smp[3].wB, b1);
+#undef WIN_STEP
+      }
 
-      if (q0 == 0) WIN_STAMP(8);                               // LDS pass of the first round done
-      if (cur_live) {
-        float* op = out + cur_pair * 32 + 8 * k;
-        __builtin_nontemporal_store(accA, reinterpret_cast<f32x4*>(op + 4 * cls_a));
-        __builtin_nontemporal_store(accB, reinterpret_cast<f32x4*>(op + 4 * (cls_a ^ 1)));
+      if (rnd == 0) WIN_STAMP(8);                              // LDS pass of the first round done
+      if (cur_live) {   // a quad writes 2 x 64 contiguous bytes
+        float* op = out + cur_pair * 32 + 4 * k;
+        __builtin_nontemporal_store(f32x4{aA0.x, aA0.y, aA1.x, aA1.y}, reinterpret_cast<f32x4*>(op + 16 * cls_a));
+        __builtin_nontemporal_store(f32x4{aB0.x, aB0.y, aB1.x, aB1.y}, reinterpret_cast<f32x4*>(op + 16 * (cls_a ^ 1)));
       }
     }
     WIN_STAMP(9);                                              // all rounds done (wave 0)
-    if (tile + G < ntiles) {                                   // odd pyramids only: another tile for this workgroup
-      __syncthreads();                                         // everybody is done with the windows and the sums
-      if (tid < 16) (&mt.sum[0][0])[tid] = 0;
-      __syncthreads();
-    }
   }
 }
 
@@ -450,11 +490,24 @@ bool win_forward_ok(const Dims& d) {
 
 int launch_forward_win(const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc, const float* attn,
                        const Dims& d, float* out, hipStream_t stream) {
-  static std::atomic<uint64_t> lds_opted_in{0};
-  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(msda_fwd_win), kLdsBytes, lds_opted_in)) return rc;
-  const int G = (d.S + 127) / 128;
-  hipLaunchKernelGGL(msda_fwd_win, dim3((unsigned)(d.M * G), (unsigned)d.N), dim3(kT), kLdsBytes, stream, value, shapes,
-                     lsi, loc, attn, d, G, out);
+  static const bool nt = std::getenv("MSDA_WIN_NT") && std::getenv("MSDA_WIN_NT")[0] == '1';   // A/B switch
+  static std::atomic<uint64_t> lds_opted_in[2] = {{0}, {0}};
+  const void* fn = nt ? reinterpret_cast<const void*>(msda_fwd_win<2>) : reinterpret_cast<const void*>(msda_fwd_win<0>);
+  if (int rc = ensure_dynamic_lds(fn, kLdsBytes, lds_opted_in[nt ? 1 : 0])) return rc;
+  // Workgroups per head.  Default: one work item per workgroup -- the host only knows S, so ceil(S / 128) per image,
+  // at least the tile count of any pyramid whose level 0 holds <= ~3/4 of the pixels; the surplus exits at once and the
+  // dispatcher staggers the rest, which keeps the memory / LDS / VALU phases of neighbouring workgroups out of step.
+  // MSDA_WIN_PERSIST=1: two resident workgroups per CU walk the items (measured slower: every workgroup of the chip
+  // enters the same phase at the same time).  Either way head m = blockIdx.x % M, i.e. (by the observed round-robin
+  // placement) XCD m only ever touches head m's slice of `value`.
+  static const bool persist = std::getenv("MSDA_WIN_PERSIST") && std::getenv("MSDA_WIN_PERSIST")[0] == '1';
+  int K = persist ? (2 * 256) / d.M : d.N * ((d.S + 127) / 128);
+  if (K < 1) K = 1;
+  const dim3 grid((unsigned)(d.M * K), 1u);
+  if (nt)
+    hipLaunchKernelGGL(msda_fwd_win<2>, grid, dim3(kT), kLdsBytes, stream, value, shapes, lsi, loc, attn, d, out);
+  else
+    hipLaunchKernelGGL(msda_fwd_win<0>, grid, dim3(kT), kLdsBytes, stream, value, shapes, lsi, loc, attn, d, out);
   return (int)hipGetLastError();
 }
 
