@@ -36,7 +36,8 @@ constexpr int kBWaves = kBT / 64;
 constexpr int kBTH = 8, kBTW = 16;                // tile in level-0 pixels
 constexpr int kBMaxL = 4, kBP = 4;
 constexpr int kBSlots = 832;                      // 104 KiB of 128-byte accumulator slots (+1 dummy slot)
-constexpr int kBPairRec = 8 * 32 + 16;            // 8 sample records per pass, padded
+constexpr int kBRec = 48;                         // one sample record: {lw, lh, a, flags} {4 value offsets} {4 LDS addresses}
+constexpr int kBPairRec = 8 * kBRec + 16;         // 8 sample records per pass, padded
 constexpr int kBWaveRec = 8 * kBPairRec;
 constexpr int kBRecBytes = kBWaves * kBWaveRec;
 constexpr int kBMaxTileQ = 256;
@@ -345,8 +346,23 @@ msda_bwd_tiled(const float* __restrict__ grad_out, const float* __restrict__ val
               }
             }
             r0[3] = __uint_as_float(flags);
-            *reinterpret_cast<f32x4*>(smem + rec_pair + j * 32) = r0;
-            *reinterpret_cast<uint2*>(smem + rec_pair + j * 32 + 16) = make_uint2(g00, l00);
+            // per-corner byte offsets into `value` (out-of-range for dead corners: the raw buffer load returns 0) and LDS
+            // accumulator addresses (the pair's sink slot for dead corners and far samples), selected HERE, once per
+            // sample, instead of in every lane of the pair at every step
+            const bool near = (flags & 16u) == 0u;
+            const uint32_t rowg = (uint32_t)Wl * pix_bytes, rowl = (uint32_t)Ww * (uint32_t)kBSlotBytes;
+            u32x4 gk, ak;
+            gk[0] = (flags & 1u) ? g00 : kOobOffset;
+            gk[1] = (flags & 2u) ? g00 + pix_bytes : kOobOffset;
+            gk[2] = (flags & 4u) ? g00 + rowg : kOobOffset;
+            gk[3] = (flags & 8u) ? g00 + rowg + pix_bytes : kOobOffset;
+            ak[0] = ((flags & 1u) && near) ? l00 : sink;
+            ak[1] = ((flags & 2u) && near) ? l00 + (uint32_t)kBSlotBytes : sink;
+            ak[2] = ((flags & 4u) && near) ? l00 + rowl : sink;
+            ak[3] = ((flags & 8u) && near) ? l00 + rowl + (uint32_t)kBSlotBytes : sink;
+            *reinterpret_cast<f32x4*>(smem + rec_pair + j * kBRec) = r0;
+            *reinterpret_cast<u32x4*>(smem + rec_pair + j * kBRec + 16) = gk;
+            *reinterpret_cast<u32x4*>(smem + rec_pair + j * kBRec + 32) = ak;
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
@@ -356,20 +372,15 @@ msda_bwd_tiled(const float* __restrict__ grad_out, const float* __restrict__ val
           //    sample s+1 are issued before the arithmetic of sample s; sched_barriers keep the compiler from
           //    hoisting further ahead (it would spill: 16 data VGPRs per sample in flight)
           uint64_t far_any = 0;
-          struct StepIn { f32x4 r0; uint2 r1; f32x4 v1, v2, v3, v4; };
+          struct StepIn { f32x4 r0; u32x4 ak; f32x4 v1, v2, v3, v4; };
           auto fetch = [&](int s8, StepIn& in) {
-            const int l = (8 * ps + s8) / P;           // compile-time
-            in.r0 = *reinterpret_cast<const f32x4*>(smem + rec_pair + s8 * 32);
-            in.r1 = *reinterpret_cast<const uint2*>(smem + rec_pair + s8 * 32 + 16);
-            const uint32_t flags = __float_as_uint(in.r0[3]);
-            const uint32_t g1 = (flags & 1u) ? in.r1.x : kOobOffset;
-            const uint32_t g2 = (flags & 2u) ? in.r1.x + pix_bytes : kOobOffset;
-            const uint32_t g3 = (flags & 4u) ? in.r1.x + lvRowG[l] : kOobOffset;
-            const uint32_t g4 = (flags & 8u) ? in.r1.x + lvRowG[l] + pix_bytes : kOobOffset;
-            in.v1 = buffer_load_f32x4(vsrc, g1 + lane_off, hoff);
-            in.v2 = buffer_load_f32x4(vsrc, g2 + lane_off, hoff);
-            in.v3 = buffer_load_f32x4(vsrc, g3 + lane_off, hoff);
-            in.v4 = buffer_load_f32x4(vsrc, g4 + lane_off, hoff);
+            in.r0 = *reinterpret_cast<const f32x4*>(smem + rec_pair + s8 * kBRec);
+            const u32x4 gk = *reinterpret_cast<const u32x4*>(smem + rec_pair + s8 * kBRec + 16);
+            in.ak = *reinterpret_cast<const u32x4*>(smem + rec_pair + s8 * kBRec + 32);
+            in.v1 = buffer_load_f32x4(vsrc, gk[0] + lane_off, hoff);
+            in.v2 = buffer_load_f32x4(vsrc, gk[1] + lane_off, hoff);
+            in.v3 = buffer_load_f32x4(vsrc, gk[2] + lane_off, hoff);
+            in.v4 = buffer_load_f32x4(vsrc, gk[3] + lane_off, hoff);
           };
           StepIn cur, nxt;
           fetch(0, cur);
@@ -382,29 +393,40 @@ msda_bwd_tiled(const float* __restrict__ grad_out, const float* __restrict__ val
             const float lw = cur.r0[0], lh = cur.r0[1], a = cur.r0[2];
             const uint32_t flags = __float_as_uint(cur.r0[3]);
             const float hw = 1.f - lw, hh = 1.f - lh;
-            const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-            float pa = 0.f, pwx = 0.f, phy = 0.f;
-            float tgs[4];   // go * a * scale: the fixed-point value-gradient of a unit-weight corner
+            // Bilinear value and its two location derivatives per channel, on channel PAIRS (v_pk_* math; the kernel is
+            // bound by VALU issue, a wave64 instruction holds its SIMD for 4 clocks whether it does one or two lanes of
+            // work):   top = v1 + lw (v2 - v1), bot = v3 + lw (v4 - v3), val = top + lh (bot - top),
+            //          d val / d y = bot - top,  d val / d x = hh (v2 - v1) + lh (v4 - v3)          (cuh:113-158, refactored)
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            v2f pa2 = {0.f, 0.f}, pw2 = {0.f, 0.f}, ph2 = {0.f, 0.f};
+            v2f tgs[2];     // go * a * scale: the fixed-point value-gradient of a unit-weight corner
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              const float tgv = go[c] * a;
-              pa += go[c] * (w1 * cur.v1[c] + w2 * cur.v2[c] + w3 * cur.v3[c] + w4 * cur.v4[c]);
-              pwx += tgv * (hh * (cur.v2[c] - cur.v1[c]) + lh * (cur.v4[c] - cur.v3[c]));
-              phy += tgv * (hw * (cur.v3[c] - cur.v1[c]) + lw * (cur.v4[c] - cur.v2[c]));
-              tgs[c] = tgv * scale;
+            for (int cp = 0; cp < 2; ++cp) {
+              const v2f V1 = {cur.v1[2 * cp], cur.v1[2 * cp + 1]}, V2 = {cur.v2[2 * cp], cur.v2[2 * cp + 1]};
+              const v2f V3 = {cur.v3[2 * cp], cur.v3[2 * cp + 1]}, V4 = {cur.v4[2 * cp], cur.v4[2 * cp + 1]};
+              const v2f G = {go[2 * cp], go[2 * cp + 1]};
+              const v2f tt = V2 - V1, tb = V4 - V3;
+              const v2f top = __builtin_elementwise_fma(v2f{lw, lw}, tt, V1), bot = __builtin_elementwise_fma(v2f{lw, lw}, tb, V3);
+              const v2f dd = bot - top;
+              const v2f val = __builtin_elementwise_fma(v2f{lh, lh}, dd, top);
+              const v2f px = __builtin_elementwise_fma(v2f{lh, lh}, tb, tt * hh);
+              const v2f TG = G * a;
+              pa2 = __builtin_elementwise_fma(G, val, pa2);
+              pw2 = __builtin_elementwise_fma(TG, px, pw2);
+              ph2 = __builtin_elementwise_fma(TG, dd, ph2);
+              tgs[cp] = TG * scale;
             }
+            const float pa = pa2.x + pa2.y, pwx = pw2.x + pw2.y, phy = ph2.x + ph2.y;
             // near samples: accumulate into the LDS window; dead corners and far samples go to the pair's sink slot
-            const bool near = (flags & 16u) == 0u;
-            const uint32_t a1 = ((flags & 1u) && near ? cur.r1.y : sink) + lane_off;
-            const uint32_t a2 = ((flags & 2u) && near ? cur.r1.y + (uint32_t)kBSlotBytes : sink) + lane_off;
-            const uint32_t a3 = ((flags & 4u) && near ? cur.r1.y + lvRowL[l] : sink) + lane_off;
-            const uint32_t a4 = ((flags & 8u) && near ? cur.r1.y + lvRowL[l] + (uint32_t)kBSlotBytes : sink) + lane_off;
+            const v2f wh = v2f{hh, lh} * hw, wl = v2f{hh, lh} * lw;      // (w1, w3), (w2, w4)
+            const uint32_t a1 = cur.ak[0] + lane_off, a2 = cur.ak[1] + lane_off, a3 = cur.ak[2] + lane_off, a4 = cur.ak[3] + lane_off;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              lds_add(a1 + 4u * c, cvt_rn_i32(w1 * tgs[c]));
-              lds_add(a2 + 4u * c, cvt_rn_i32(w2 * tgs[c]));
-              lds_add(a3 + 4u * c, cvt_rn_i32(w3 * tgs[c]));
-              lds_add(a4 + 4u * c, cvt_rn_i32(w4 * tgs[c]));
+            for (int cp = 0; cp < 2; ++cp) {
+              const v2f g1 = tgs[cp] * wh.x, g2 = tgs[cp] * wl.x, g3 = tgs[cp] * wh.y, g4 = tgs[cp] * wl.y;
+              lds_add(a1 + 8u * cp, cvt_rn_i32(g1.x)); lds_add(a1 + 8u * cp + 4u, cvt_rn_i32(g1.y));
+              lds_add(a2 + 8u * cp, cvt_rn_i32(g2.x)); lds_add(a2 + 8u * cp + 4u, cvt_rn_i32(g2.y));
+              lds_add(a3 + 8u * cp, cvt_rn_i32(g3.x)); lds_add(a3 + 8u * cp + 4u, cvt_rn_i32(g3.y));
+              lds_add(a4 + 8u * cp, cvt_rn_i32(g4.x)); lds_add(a4 + 8u * cp + 4u, cvt_rn_i32(g4.y));
             }
             far_any |= __ballot((flags & 16u) != 0u);
             const float ra = group8_sum(pa);
@@ -426,7 +448,7 @@ msda_bwd_tiled(const float* __restrict__ grad_out, const float* __restrict__ val
             const int hl = lane & 31;
 #pragma unroll 1
             for (int s8 = 0; s8 < 8; ++s8) {
-              const uint32_t myflags = __float_as_uint(*reinterpret_cast<const float*>(smem + rec_pair + s8 * 32 + 12));
+              const uint32_t myflags = __float_as_uint(*reinterpret_cast<const float*>(smem + rec_pair + s8 * kBRec + 12));
               const uint64_t fmask = __ballot((myflags & 16u) != 0u);
               if (fmask == 0) continue;                  // wave-uniform
               const int l = (8 * ps + s8) / P;
@@ -436,21 +458,18 @@ msda_bwd_tiled(const float* __restrict__ grad_out, const float* __restrict__ val
                 const bool act = hm != 0u;
                 const int first = act ? (__builtin_ctz(hm) & ~7) : 0;          // first lane of the far pair in this half
                 const int fp = ((lane & 32) + first) >> 3;                     // that pair's index in the wave
-                const uint32_t rp = kBWinBytes + wv * kBWaveRec + fp * kBPairRec + s8 * 32;
+                const uint32_t rp = kBWinBytes + wv * kBWaveRec + fp * kBPairRec + s8 * kBRec;
                 const f32x4 r0 = *reinterpret_cast<const f32x4*>(smem + rp);
-                const uint2 r1 = *reinterpret_cast<const uint2*>(smem + rp + 16);
+                const u32x4 gk = *reinterpret_cast<const u32x4*>(smem + rp + 16);   // kOobOffset marks a dead corner
                 const int fqi = it * (kBWaves * 8) + wv * 8 + fp;
                 const int fpair = (act && fqi < nround) ? mt.qtab[fqi] * M + m : 0;
                 const float g = act ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
                                           gsrc, (uint32_t)fpair * 128u + (uint32_t)hl * 4u, 0, 0)) : 0.f;
-                const uint32_t flags = __float_as_uint(r0[3]);
                 const float lw = r0[0], lh = r0[1], tgv = g * r0[2];
-                // corner offsets in 32-bit modular arithmetic (g00 is "virtual" when the top-left corner is dead)
-                const uint32_t o1 = r1.x, o2 = r1.x + pix_bytes, o3 = r1.x + rowg, o4 = r1.x + rowg + pix_bytes;
-                if (act && (flags & 1u)) atomic_add(reinterpret_cast<float*>(gv_head + o1) + hl, (1.f - lh) * (1.f - lw) * tgv);
-                if (act && (flags & 2u)) atomic_add(reinterpret_cast<float*>(gv_head + o2) + hl, (1.f - lh) * lw * tgv);
-                if (act && (flags & 4u)) atomic_add(reinterpret_cast<float*>(gv_head + o3) + hl, lh * (1.f - lw) * tgv);
-                if (act && (flags & 8u)) atomic_add(reinterpret_cast<float*>(gv_head + o4) + hl, lh * lw * tgv);
+                if (act && gk[0] != kOobOffset) atomic_add(reinterpret_cast<float*>(gv_head + gk[0]) + hl, (1.f - lh) * (1.f - lw) * tgv);
+                if (act && gk[1] != kOobOffset) atomic_add(reinterpret_cast<float*>(gv_head + gk[1]) + hl, (1.f - lh) * lw * tgv);
+                if (act && gk[2] != kOobOffset) atomic_add(reinterpret_cast<float*>(gv_head + gk[2]) + hl, lh * (1.f - lw) * tgv);
+                if (act && gk[3] != kOobOffset) atomic_add(reinterpret_cast<float*>(gv_head + gk[3]) + hl, lh * lw * tgv);
                 if (act) hm &= ~(0xFFu << first);
               }
             }
