@@ -91,5 +91,64 @@ def main():
         print(name, tuple(src.shape), "->", tuple(out.shape))
 
 
+STACK_LEVELS = [(24, 33), (12, 17), (6, 9), (3, 5)]       # S = 1065 >= 1024: the encoder-sized kernels of the HIP path
+STACK_LAYERS = 6
+
+
+def stack_inputs(dtype=torch.float64):
+    """Seeded inputs and parameters of the 6-layer stack (shared with tests/test_encoder_layer_gpu.py: only the
+    reference's output is stored, the 4.7 M parameters are re-drawn from the same CPU generator on both sides and
+    pinned by a digest)."""
+    g = torch.Generator().manual_seed(2024)
+    S = sum(h * w for h, w in STACK_LEVELS)
+    src = torch.randn(1, S, 256, generator=g, dtype=torch.float64)
+    pos = torch.randn(1, S, 256, generator=g, dtype=torch.float64) * 0.5
+    ref = torch.rand(1, S, 4, 2, generator=g, dtype=torch.float64)
+    params = []
+    for _ in range(STACK_LAYERS):
+        p = {}
+        def lin(name, o, i, wstd):
+            p[name + ".weight"] = torch.randn(o, i, generator=g, dtype=torch.float64) * wstd
+            p[name + ".bias"] = torch.randn(o, generator=g, dtype=torch.float64) * 0.1
+        lin("self_attn.sampling_offsets", 256, 256, 0.02)
+        lin("self_attn.attention_weights", 128, 256, 0.1)
+        lin("self_attn.value_proj", 256, 256, 1.0 / 16)
+        lin("self_attn.output_proj", 256, 256, 1.0 / 16)
+        lin("linear1", 1024, 256, 1.0 / 16)
+        lin("linear2", 256, 1024, 1.0 / 32)
+        for n in ("norm1", "norm2"):
+            p[n + ".weight"] = 1.0 + 0.1 * torch.randn(256, generator=g, dtype=torch.float64)
+            p[n + ".bias"] = 0.1 * torch.randn(256, generator=g, dtype=torch.float64)
+        # the MSDeformAttn bias pattern of the offsets (one direction per head x point index) on top of the noise
+        theta = torch.arange(8, dtype=torch.float64) * (2.0 * torch.pi / 8)
+        grid = torch.stack([theta.cos(), theta.sin()], -1)
+        grid = (grid / grid.abs().max(-1, keepdim=True)[0]).view(8, 1, 1, 2).repeat(1, 4, 4, 1)
+        grid = grid * torch.arange(1, 5, dtype=torch.float64).view(1, 1, 4, 1)
+        p["self_attn.sampling_offsets.bias"] = p["self_attn.sampling_offsets.bias"] + grid.reshape(-1)
+        params.append({k: v.to(dtype) for k, v in p.items()})
+    digest = float(sum(float(v.double().abs().sum()) for p in params for v in p.values()))
+    shapes = torch.as_tensor(STACK_LEVELS, dtype=torch.long)
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    return src.to(dtype), pos.to(dtype), ref.to(dtype), shapes, lsi, params, digest
+
+
+def stack():
+    """Six DISTINCT reference encoder layers back to back (what DeformableTransformerEncoder.forward does,
+    deformable_transformer_dino.py:303-327, without the text-fusion branch), d_model 256 / 8 heads / d_ffn 1024, in
+    fp64: the fixture that bounds how the split-bf16 projections of the HIP inference path compound over the stack."""
+    cls = load_reference_layer()
+    src, pos, ref, shapes, lsi, params, digest = stack_inputs()
+    out = src
+    with torch.no_grad():
+        for p in params:
+            layer = cls(d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4, n_heads=8, n_points=4).double().eval()
+            layer.load_state_dict(p)
+            out = layer(out, pos, ref, shapes, lsi, None)
+    np.savez_compressed(os.path.join(HERE, "encstack_6layers.npz"), out=out.numpy().astype(np.float32),
+                        digest=np.float64(digest))
+    print("encstack_6layers", tuple(out.shape), "scale", float(out.abs().max()), "digest", digest)
+
+
 if __name__ == "__main__":
     main()
+    stack()

@@ -152,3 +152,44 @@ def test_layer_is_hip_graph_capturable(dev):
         torch.cuda.synchronize()
         del graph                                   # release the captured graph while the runtime is fully alive
     assert same
+
+
+def test_six_layer_stack_vs_reference_fixture(dev):
+    """Six distinct encoder layers back to back (d_model 256, 8 heads, d_ffn 1024, S = 1065) against the reference's
+    own layers run in fp64 (tests/golden/make_encoder_layer_golden.py::stack).  Bounds how the per-layer error of the
+    default inference path (split-bf16 projections, ~2e-5 of the output scale per GEMM) compounds over the stack:
+    1e-4 of the output scale, the parity bound of BASELINE.json's north_star, must hold for the STACK, not per layer.
+    The exact-fp32 route (fast_linear = False) is held to the same bound with a wide margin."""
+    import importlib.util
+    import os
+    from uninext_amd.modules import DeformableTransformerEncoderLayer, MSDeformAttn
+    spec = importlib.util.spec_from_file_location(
+        "make_encoder_layer_golden", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_encoder_layer_golden.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    g = load_golden("encstack_6layers")
+    src, pos, ref, shapes, lsi, params, digest = gen.stack_inputs(torch.float32)
+    assert abs(digest - float(g["digest"])) < 1e-6 * float(g["digest"]), "parameter generator drifted from the fixture"
+    layers = []
+    for p in params:
+        layer = DeformableTransformerEncoderLayer(d_model=256, d_ffn=1024, n_heads=8)
+        layer.load_state_dict(p)
+        layers.append(layer.to(dev).eval())
+    src, pos, ref, shapes, lsi = (t.to(dev) for t in (src, pos, ref, shapes, lsi))
+    want = g["out"].astype(np.float64)
+    scale = float(np.abs(want).max())
+    errs = {}
+    for fast in (True, False):
+        old = MSDeformAttn.fast_linear
+        MSDeformAttn.fast_linear = fast
+        try:
+            with torch.no_grad():
+                x = src
+                for layer in layers:
+                    x = layer(x, pos, ref, shapes, lsi, None)
+        finally:
+            MSDeformAttn.fast_linear = old
+        errs[fast] = max_abs(x.cpu().numpy(), want) / scale
+    print("six-layer stack, error / output scale: split-bf16 %.2e, exact fp32 %.2e" % (errs[True], errs[False]))
+    assert errs[False] < 2e-5, errs
+    assert errs[True] < 1e-4, errs

@@ -451,8 +451,6 @@ msda_bwd_tiled(const float* __restrict__ grad_out, const float* __restrict__ val
               const uint32_t myflags = __float_as_uint(*reinterpret_cast<const float*>(smem + rec_pair + s8 * kBRec + 12));
               const uint64_t fmask = __ballot((myflags & 16u) != 0u);
               if (fmask == 0) continue;                  // wave-uniform
-              const int l = (8 * ps + s8) / P;
-              const uint32_t rowg = l == 0 ? lvRowG[0] : (l == 1 ? lvRowG[1] : (l == 2 ? lvRowG[2] : lvRowG[3]));
               uint32_t hm = (lane < 32) ? (uint32_t)fmask : (uint32_t)(fmask >> 32);
               while (__ballot(hm != 0u)) {
                 const bool act = hm != 0u;
