@@ -10,8 +10,8 @@
 //   grad_loc.y              = H * a * sum_c g_c * (hw (v3 - v1) + lw (v4 - v2))
 //
 // Kernels
-//   msda_bwd_generic<T>      any D/L/P, float or double: one wave64 per (query, head) pair, lanes
-//                            stride the channels, wave-shuffle reduction.  One kernel instead of the
+//   msda_bwd_generic<T,HALF> any D/L/P, float or double: one wave64 (D > 32) or half a wave (D <= 32) per (query,
+//                            head) pair, lanes stride the channels, shuffle reduction.  One kernel instead of the
 //                            reference's six D-specific ones; this is what fp64 gradcheck runs on.
 //   msda_bwd_lanegroup<G,LP> fp32, D = 4*G: same work split as msda_fwd_lanegroup (G lanes per pair,
 //                            4 channels per lane, setup shared through LDS records); the three
@@ -21,18 +21,30 @@
 
 namespace msda {
 
-template <typename T>
+// HALF = 1: D <= 32, a wave carries TWO pairs (32 lanes each) -- at the UNINEXT head size a whole wave per pair would
+// leave half the lanes idle; the three reductions then stay inside a half-wave.
+template <typename T, int HALF>
 __global__ void __launch_bounds__(kBlock)
 msda_bwd_generic(const T* __restrict__ grad_out, const T* __restrict__ value,
                  const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
                  const T* __restrict__ loc, const T* __restrict__ attn, Dims d,
                  T* __restrict__ grad_value, T* __restrict__ grad_loc, T* __restrict__ grad_attn) {
-  const int lane = threadIdx.x & 63;
+  constexpr int kLanes = HALF ? 32 : 64;                   // lanes per pair
+  constexpr int kPairsPerBlock = kBlock / kLanes;
+  const int lane = threadIdx.x & (kLanes - 1);
   const int64_t n_pairs = (int64_t)d.N * d.Lq * d.M;
   const int64_t pix_stride = (int64_t)d.M * d.D;
   const int LP = d.L * d.P;
-  for (int64_t pair = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); pair < n_pairs;
-       pair += (int64_t)gridDim.x * (kBlock / 64)) {
+  auto group_sum = [](T v) {
+#pragma unroll
+    for (int o = kLanes / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  };
+  for (int64_t pair0 = (int64_t)blockIdx.x * kPairsPerBlock + threadIdx.x / kLanes; ; pair0 += (int64_t)gridDim.x * kPairsPerBlock) {
+    // the two halves of a wave run in lock step: a half past the end idles through the loop with `live` off
+    const bool live = pair0 < n_pairs;
+    if (!__ballot(live)) break;
+    const int64_t pair = live ? pair0 : 0;
     const int m = (int)(pair % d.M);
     const int64_t b = pair / ((int64_t)d.M * d.Lq);
     const T* g_ptr = grad_out + pair * d.D;
@@ -44,30 +56,33 @@ msda_bwd_generic(const T* __restrict__ grad_out, const T* __restrict__ value,
         const T a = attn[si];
         const Sample<T> s = make_sample<T>(loc[si * 2], loc[si * 2 + 1], H, W);
         T pa = 0, pw = 0, ph = 0;
-        if (s.in_range) {  // wave-uniform branch
-          const int64_t o1 = lvl_off + ((int64_t)s.h_low * W + s.w_low) * pix_stride;
-          const int64_t o2 = o1 + pix_stride, o3 = o1 + (int64_t)W * pix_stride, o4 = o3 + pix_stride;
-          const T w1 = s.hh * s.hw, w2 = s.hh * s.lw, w3 = s.lh * s.hw, w4 = s.lh * s.lw;
-          for (int c = lane; c < d.D; c += 64) {
-            const T g = g_ptr[c];
-            const T tgv = g * a;
-            const T v1 = s.ok1 ? value[o1 + c] : (T)0;
-            const T v2 = s.ok2 ? value[o2 + c] : (T)0;
-            const T v3 = s.ok3 ? value[o3 + c] : (T)0;
-            const T v4 = s.ok4 ? value[o4 + c] : (T)0;
-            if (s.ok1) atomic_add(grad_value + o1 + c, w1 * tgv);
-            if (s.ok2) atomic_add(grad_value + o2 + c, w2 * tgv);
-            if (s.ok3) atomic_add(grad_value + o3 + c, w3 * tgv);
-            if (s.ok4) atomic_add(grad_value + o4 + c, w4 * tgv);
-            pa += g * (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4);
-            pw += tgv * (s.hh * (v2 - v1) + s.lh * (v4 - v3));
-            ph += tgv * (s.hw * (v3 - v1) + s.lw * (v4 - v2));
+        const bool in = live && s.in_range;
+        if (__ballot(in)) {  // wave-uniform branch (the reductions below need every lane of the group)
+          if (in) {
+            const int64_t o1 = lvl_off + ((int64_t)s.h_low * W + s.w_low) * pix_stride;
+            const int64_t o2 = o1 + pix_stride, o3 = o1 + (int64_t)W * pix_stride, o4 = o3 + pix_stride;
+            const T w1 = s.hh * s.hw, w2 = s.hh * s.lw, w3 = s.lh * s.hw, w4 = s.lh * s.lw;
+            for (int c = lane; c < d.D; c += kLanes) {
+              const T g = g_ptr[c];
+              const T tgv = g * a;
+              const T v1 = s.ok1 ? value[o1 + c] : (T)0;
+              const T v2 = s.ok2 ? value[o2 + c] : (T)0;
+              const T v3 = s.ok3 ? value[o3 + c] : (T)0;
+              const T v4 = s.ok4 ? value[o4 + c] : (T)0;
+              if (s.ok1) atomic_add(grad_value + o1 + c, w1 * tgv);
+              if (s.ok2) atomic_add(grad_value + o2 + c, w2 * tgv);
+              if (s.ok3) atomic_add(grad_value + o3 + c, w3 * tgv);
+              if (s.ok4) atomic_add(grad_value + o4 + c, w4 * tgv);
+              pa += g * (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4);
+              pw += tgv * (s.hh * (v2 - v1) + s.lh * (v4 - v3));
+              ph += tgv * (s.hw * (v3 - v1) + s.lw * (v4 - v2));
+            }
           }
-          pa = wave_sum(pa);
-          pw = wave_sum(pw);
-          ph = wave_sum(ph);
+          pa = group_sum(pa);
+          pw = group_sum(pw);
+          ph = group_sum(ph);
         }
-        if (lane == 0) {
+        if (live && lane == 0) {
           grad_attn[si] = pa;
           grad_loc[si * 2] = (T)W * pw;
           grad_loc[si * 2 + 1] = (T)H * ph;
@@ -276,10 +291,16 @@ static int launch_generic(const T* grad_out, const T* value, const int64_t* shap
                           const T* attn, const Dims& d, T* grad_value, T* grad_loc, T* grad_attn,
                           hipStream_t stream) {
   const int64_t n_pairs = (int64_t)d.N * d.Lq * d.M;
-  const int64_t want = (n_pairs + (kBlock / 64) - 1) / (kBlock / 64);
+  const bool half = d.D <= 32;                              // two pairs per wave
+  const int per_block = half ? kBlock / 32 : kBlock / 64;
+  const int64_t want = (n_pairs + per_block - 1) / per_block;
   const unsigned blocks = (unsigned)(want < 65536 * 16 ? want : 65536 * 16);
-  hipLaunchKernelGGL(msda_bwd_generic<T>, dim3(blocks), dim3(kBlock), 0, stream, grad_out, value, shapes, lsi, loc,
-                     attn, d, grad_value, grad_loc, grad_attn);
+  if (half)
+    hipLaunchKernelGGL((msda_bwd_generic<T, 1>), dim3(blocks), dim3(kBlock), 0, stream, grad_out, value, shapes, lsi, loc,
+                       attn, d, grad_value, grad_loc, grad_attn);
+  else
+    hipLaunchKernelGGL((msda_bwd_generic<T, 0>), dim3(blocks), dim3(kBlock), 0, stream, grad_out, value, shapes, lsi, loc,
+                       attn, d, grad_value, grad_loc, grad_attn);
   return (int)hipGetLastError();
 }
 
