@@ -25,13 +25,14 @@
 //   pair, DPP reductions for grad_attn / grad_loc, coalesced 16/8-byte gradient stores.  `value` itself is read
 //   through the L1 path (raw buffer loads, out-of-range offset = 0 for dead corners).
 //
-// One 1024-thread workgroup per CU (16 waves = 4 per SIMD), persistent grid of 256, items walked head-minor.
+// One 768-thread workgroup per CU (12 waves = 3 per SIMD), persistent grid of 256, items walked head-minor.
 // Sample records are built 8 samples at a time (two passes per query) to keep the record LDS at 34 KB.
 #include "msda_common.hpp"
 
 namespace msda {
 
-constexpr int kBT = 512;                          // threads per workgroup
+constexpr int kBT = 768;                          // threads per workgroup: 12 waves = 3 per SIMD (168 VGPRs); 512 threads were
+                                                  // 463 -> 418 us after the step diet, 768 give 353 us: the step is a latency chain
 constexpr int kBWaves = kBT / 64;
 constexpr int kBTH = 8, kBTW = 16;                // tile in level-0 pixels
 constexpr int kBMaxL = 4, kBP = 4;
@@ -96,7 +97,7 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-__global__ void __launch_bounds__(kBT, 2)
+__global__ void __launch_bounds__(kBT, 3)
 msda_bwd_tiled(const float* __restrict__ grad_out, const float* __restrict__ value,
                const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
                const float* __restrict__ loc, const float* __restrict__ attn, Dims d,
@@ -438,7 +439,7 @@ msda_bwd_tiled(const float* __restrict__ grad_out, const float* __restrict__ val
             } else {
               gl[2] = mine ? rw : gl[2]; gl[3] = mine ? rh : gl[3]; ga1 = mine ? ra : ga1;
             }
-            __builtin_amdgcn_sched_barrier(0);
+            // (no scheduling barrier at the end of a step: the next step's arithmetic may overlap this one's LDS atomics)
             cur = nxt;
           }
           // -- far samples of this pass: the value gradient w_k * a * g_c does not depend on the sampled values,
