@@ -26,6 +26,8 @@ Extra objects on the JSON line (all measured in this run, after the timed region
                 sources (sha256 of uninext_amd/csrc); null otherwise.
   flavours      encoder-forward launch time (us) on the two other location distributions: `uniform`
                 (ops/test.py:34, no locality) and `wide` (model-like with sigma = 6 px offsets).
+  window_kernel the opt-in LDS-window forward kernel (msda_fwd_win) on the headline inputs and on the two other
+                flavours -- not what `auto` runs: it wins only when the samples stay near their query.
   backward      BASELINE configs[4] (training step): the encoder-call and the decoder-call backward launches
                 (grad_value pre-zeroed outside the events): kernel, launch_us, algorithmic bytes
                 (N*(2048*S + 4096*Lq)), achieved GB/s, fraction of 8 TB/s, traffic (as above, or null).
@@ -191,6 +193,42 @@ def measure_flavours(rank, reps=12):
             call(xs[k[0] % len(xs)])
         out[fl] = {"launch_us": time_events(one, reps), "kernel": _lib.last_kernel("forward")}
         del xs
+    return out
+
+
+def measure_window_kernel(enc, reps=12):
+    """The opt-in LDS-window forward (msda_fwd_win, MSDA_HIP_FWD_VARIANT=9) on the headline inputs: faster than the
+    default when the samples of a tile stay near it (this flavour), slower when they do not -- see `flavours` -- and the
+    host cannot tell which without looking at the locations, so `auto` does not take it (profiles/r02_window_forward_experiments.txt)."""
+    out = {}
+    _lib.set_variant("forward", "msda_fwd_win")
+    try:
+        for x in enc[:3]:
+            call(x)
+        k = [0]
+
+        def one():
+            k[0] += 1
+            call(enc[k[0] % len(enc)])
+        us = time_events(one, reps)
+        kern = _lib.last_kernel("forward")
+        S = enc[0]["value"].shape[1]
+        alg = workloads.algorithmic_bytes_forward(BATCH, S, S)
+        out = {"kernel": kern, "launch_us": us, "achieved": alg / us / 1e3, "unit": "GB/s", "frac": alg / us / 1e3 / HBM_PEAK_GBS,
+               "traffic": committed_traffic(kern, "forward_encoder_window"), "selected_by": "msda_hip_set_variant(0, 9)"}
+        for fl in ("uniform", "wide"):
+            xs = [workloads.make_inputs("encoder", batch=BATCH, seed=70 + i, **flavour_kwargs(fl)) for i in range(2)]
+            for x in xs:
+                call(x)
+            j = [0]
+
+            def other():
+                j[0] += 1
+                call(xs[j[0] % len(xs)])
+            out[fl + "_launch_us"] = time_events(other, 6)
+            del xs
+    finally:
+        _lib.set_variant("forward", "auto")
     return out
 
 
@@ -391,6 +429,8 @@ def main():
     if not args.no_extras:   # every rank takes part (collectives inside), rank 0 reports
         if "flavours" in want:
             extras["flavours"] = measure_flavours(rank)
+            if args.flavour == "model":
+                extras["window_kernel"] = measure_window_kernel(enc)
         if "backward" in want:
             extras["backward"] = measure_backward(enc, dec)
         if "train" in want:

@@ -40,6 +40,15 @@ int dynmask_hip_forward_f32(const float* mask_feats, const float* inst_xy, const
                             int rel_coord, float* out_logits, void* stream);
 
 /*
+ * Kernel behind dynmask_hip_forward_f32: 0 = auto (the faster one measured on MI355X), 1 = packed-FMA VALU kernel,
+ * 2 / 3 = MFMA kernel (v_mfma_f32_4x4x1_16b_f32; 2 / 4 pixels per lane).  The environment variable
+ * DYNMASK_HIP_VARIANT seeds the choice.  Returns 0 or DYNMASK_ERR_BAD_DIMS.  dynmask_hip_last_kernel names the
+ * kernel the last forward call enqueued ("dynmask_fwd_pkfma", "dynmask_fwd_mfma_q2", "dynmask_fwd_mfma_q4").
+ */
+int dynmask_hip_set_variant(int variant);
+const char* dynmask_hip_last_kernel(void);
+
+/*
  * aligned_bilinear (ddetrs_dn.py:1174-1196): in [n, h, w] -> out [n, factor*h, factor*w]; factor >= 1.
  */
 int aligned_bilinear_hip_f32(const float* in, int n, int h, int w, int factor, float* out, void* stream);

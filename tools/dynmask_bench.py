@@ -36,6 +36,20 @@ def main():
     xy, pr = ref.reshape(-1, 2).contiguous(), params.flatten(0, 1).contiguous()
     flop = 2.0 * 152 * n_all * H * W
     with torch.no_grad():
+        from uninext_amd import _lib
+        lib = _lib.load()
+        base = None
+        for v in (1, 2, 3):      # A/B of the kernels behind the same entry point (include/dynmask_hip.h)
+            lib.dynmask_hip_set_variant(v)
+            o = ext.dynmask_forward(feats, xy, pr, num_insts, 8, True)
+            name = lib.dynmask_hip_last_kernel().decode()
+            us_v = timeit(lambda: ext.dynmask_forward(feats, xy, pr, num_insts, 8, True))
+            base = o if base is None else base
+            print("  variant %d %-22s %9.1f us  %6.1f TFLOP/s (%.1f%% of 157.3 TF)  max |diff| vs variant 1 %.3g"
+                  % (v, name, us_v, flop / us_v / 1e6, flop / us_v / 1e6 / 1.573, float((o - base).abs().max())))
+        lib.dynmask_hip_set_variant(0)
+        if "--ab-only" in sys.argv:
+            return
         us = timeit(lambda: ext.dynmask_forward(feats, xy, pr, num_insts, 8, True))
         print("dynmask_hip_forward_f32      %9.1f us  %6.1f TFLOP/s (%.1f%% of the 157.3 TF fp32 VALU peak), %.0f GB/s written"
               % (us, flop / us / 1e6, flop / us / 1e6 / 1.573, n_all * H * W * 4 / us / 1e3))

@@ -7,8 +7,8 @@ doubled (gfx950 tallies the 128-byte read requests of wide loads as 64 B), per l
 
 Runs on the GPU box (from the repository root; rocprofv3 output goes to gpurun_out/traffic_prof).  The parent
 starts `rocprofv3 ... -- python tools/measure_traffic.py --child` once per counter set; the child launches, in this
-order and separated by a marker kernel, `reps` encoder forward calls, `reps` encoder backward calls and `reps`
-decoder backward calls (BASELINE configs[1] / configs[4] shapes, model-like locations, rotating input sets).
+order and separated by a marker kernel, `reps` encoder forward calls (default kernel), `reps` with the opt-in window
+kernel, `reps` encoder backward calls and `reps` decoder backward calls (BASELINE configs[1] / configs[4] shapes, model-like locations, rotating input sets).
 The parent splits the dispatch-ordered counter rows into one run of msda:: kernels per call and writes
 
     {"source_hash": <bench.kernel_source_hash()>, "git": <HEAD>, "entries": {"forward_encoder": {"kernel": ...,
@@ -25,7 +25,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-PHASES = ("forward_encoder", "backward_encoder", "backward_decoder")
+PHASES = ("forward_encoder", "forward_encoder_window", "backward_encoder", "backward_decoder")
 SQ_COUNTERS = ["SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS",
                "SQ_INSTS_VALU", "SQ_INSTS_VMEM_RD", "SQ_LDS_BANK_CONFLICT"]
 
@@ -40,8 +40,8 @@ def child(reps):
     dec = [workloads.make_inputs("decoder", "model", batch=2, seed=350 + i) for i in range(3)]
     names = {}
     # one untimed call of each kind first (dynamic-LDS opt-in, lazy module load) -- also separated by markers
-    for phase in range(3):
-        xs = enc if phase < 2 else dec
+    for phase in range(4):
+        xs = enc if phase < 3 else dec
         bufs = []
         for i, x in enumerate(xs):
             g = torch.Generator().manual_seed(400 + i)
@@ -51,12 +51,14 @@ def child(reps):
             x, b = xs[r % 3], bufs[r % 3]
             b[1].zero_()
             marker.add_(1.0)
-            if phase == 0:
+            if phase < 2:
+                _lib.set_variant("forward", "msda_fwd_win" if phase == 1 else "auto")
                 bench.call(x)
+                _lib.set_variant("forward", "auto")
             else:
                 bench.backward_call(x, *b)
             marker.add_(1.0)
-        names[PHASES[phase]] = _lib.last_kernel("forward" if phase == 0 else "backward")
+        names[PHASES[phase]] = _lib.last_kernel("forward" if phase < 2 else "backward")
         del bufs
     torch.cuda.synchronize()
     print("CHILD_KERNELS " + json.dumps(names), flush=True)
@@ -109,8 +111,8 @@ def profile(pmc, reps, outdir, tag):
         if line.startswith("CHILD_KERNELS "):
             names = json.loads(line[len("CHILD_KERNELS "):])
     calls = runs_of_calls(find_db(d))
-    if len(calls) != 3 * (reps + 1):
-        raise SystemExit("expected %d msda calls in the trace, found %d" % (3 * (reps + 1), len(calls)))
+    if len(calls) != len(PHASES) * (reps + 1):
+        raise SystemExit("expected %d msda calls in the trace, found %d" % (len(PHASES) * (reps + 1), len(calls)))
     per_phase = {}
     for p, phase in enumerate(PHASES):
         sel = calls[p * (reps + 1) + 1:(p + 1) * (reps + 1)]      # drop the warm-up call
@@ -136,6 +138,7 @@ def main():
     _, write = profile(["WRITE_SIZE"], args.reps, args.workdir, "write")
     S = sum(h * w for h, w in workloads.R50_LEVELS_INFER)
     alg = {"forward_encoder": workloads.algorithmic_bytes_forward(2, S, S),
+           "forward_encoder_window": workloads.algorithmic_bytes_forward(2, S, S),
            "backward_encoder": workloads.algorithmic_bytes_backward(2, S, S),
            "backward_decoder": workloads.algorithmic_bytes_backward(2, S, 900)}
     try:

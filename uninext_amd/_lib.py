@@ -16,7 +16,8 @@ EXPORTS = (
     "msda_hip_set_variant", "msda_hip_get_variant", "msda_hip_variant_name", "msda_hip_last_kernel",
 )
 
-DYNMASK_EXPORTS = ("dynmask_hip_forward_f32", "aligned_bilinear_hip_f32")   # include/dynmask_hip.h
+DYNMASK_EXPORTS = ("dynmask_hip_forward_f32", "aligned_bilinear_hip_f32", "dynmask_hip_set_variant",
+                   "dynmask_hip_last_kernel")   # include/dynmask_hip.h
 PATCH_EMBED_EXPORTS = ("patch_embed_hip_f32", "patch_embed_hip_packed_weight_bytes", "patch_embed_hip_pack_weight_f32",
                        "patch_embed_hip_packed_f32")                           # include/patch_embed_hip.h
 LINEAR_EXPORTS = ("linear_hip_packed_weight_bytes", "linear_hip_pack_weight_f32", "linear_hip_packed_f32",
@@ -74,6 +75,8 @@ def load():
     lib.dynmask_hip_forward_f32.argtypes = [p, p, p, p, i, i, i, i, i, i, p, p]
     lib.dynmask_hip_forward_f32.restype = i
     lib.aligned_bilinear_hip_f32.argtypes, lib.aligned_bilinear_hip_f32.restype = [p, i, i, i, i, p, p], i
+    lib.dynmask_hip_set_variant.argtypes, lib.dynmask_hip_set_variant.restype = [i], i
+    lib.dynmask_hip_last_kernel.argtypes, lib.dynmask_hip_last_kernel.restype = [], s
     lib.patch_embed_hip_f32.argtypes, lib.patch_embed_hip_f32.restype = [p, p, p, i, i, i, i, i, i, i, p, p], i
     lib.patch_embed_hip_packed_weight_bytes.argtypes = [i, i, i]
     lib.patch_embed_hip_packed_weight_bytes.restype = ctypes.c_size_t
