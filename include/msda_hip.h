@@ -163,6 +163,21 @@ const char* msda_hip_variant_name(int which, int variant); /* NULL past the last
  */
 const char* msda_hip_last_kernel(int which);
 
+/*
+ * Automatic choice of the fp32 forward kernel on the encoder shape (num_query == spatial_size, channels 32, 4 levels
+ * x 4 points): the LDS-window kernel (msda_fwd_win) is faster than the gather kernel (msda_fwd_lg3) while the samples
+ * of a query stay within a few pixels of it and slower when they do not, and only the sampling locations tell.  Every
+ * launch of the window kernel counts the samples that missed their tile's windows and its last workgroup stores the
+ * count in host-mapped memory; variant 0 (automatic) follows the latest report -- window kernel while the far
+ * fraction is <= 0.25 -- and, while it runs the gather kernel, sends every 64th call through the window kernel to
+ * refresh the report.  The choice never changes a result beyond fp32 summation order.  MSDA_HIP_FWD_ADAPTIVE=0 in
+ * the environment pins variant 0 to the gather kernel.
+ *
+ * msda_hip_forward_locality: number of reports received so far on the current device (0: none yet; the report of a
+ * launch lands when that launch completes) and, in *far_fraction (may be NULL), the far fraction of the latest one.
+ */
+int msda_hip_forward_locality(double* far_fraction);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,6 +21,33 @@ def test_hip_path_matches_reference(name):
     assert float(np.abs(out.cpu().numpy() - g["out"]).max()) < 1e-4 * max(1.0, float(np.abs(g["out"]).max()))
 
 
+@pytest.mark.parametrize("variant", [2, 3])
+@pytest.mark.parametrize("rel", [True, False])
+def test_mfma_variants_equal_the_packed_fma_kernel(variant, rel):
+    """The MFMA form (include/dynmask_hip.h: dynmask_hip_set_variant) is the same fmaf chain: bitwise equal, with and
+    without relative coordinates, on an image whose pixel count is not a multiple of the chunk (tail lanes)."""
+    from uninext_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11)
+    H, W = 37, 53
+    num_insts = [5, 0, 9]
+    n_all = sum(num_insts)
+    feats = torch.randn(3, 8, H, W, generator=g).to(DEV)
+    xy = (torch.rand(n_all, 2, generator=g) * torch.tensor([W * 8.0, H * 8.0])).to(DEV)
+    params = (torch.randn(n_all, 169 if rel else 153, generator=g) * 0.3).to(DEV)
+    try:
+        assert lib.dynmask_hip_set_variant(1) == 0
+        base = ext.dynmask_forward(feats, xy, params, num_insts, 8, rel)
+        assert lib.dynmask_hip_last_kernel().decode() == "dynmask_fwd_pkfma"
+        assert lib.dynmask_hip_set_variant(variant) == 0
+        out = ext.dynmask_forward(feats, xy, params, num_insts, 8, rel)
+        assert lib.dynmask_hip_last_kernel().decode() == "dynmask_fwd_mfma_q%d" % (2 if variant == 2 else 4)
+        assert torch.equal(out, base)
+        assert lib.dynmask_hip_set_variant(99) != 0
+    finally:
+        lib.dynmask_hip_set_variant(0)
+
+
 @pytest.mark.parametrize("factor", [1, 2, 3, 4])
 def test_hip_aligned_bilinear(factor):
     g = load_golden("dynmask_aligned_bilinear")

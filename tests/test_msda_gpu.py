@@ -128,7 +128,8 @@ def test_quarter_scale_r50_vs_oracle(kind, flavour, dev, api):
     x = workloads.make_inputs(kind, flavour, batch=2, levels=levels, num_query=None if kind == "encoder" else 300,
                               seed=21, device=dev)
     out = MSDA.ms_deform_attn_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], 64)
-    assert lib.last_kernel("forward") == ("msda_fwd_lg3" if x["loc"].shape[1] >= 1024 else "msda_fwd_lanegroup")
+    # encoder shape: the automatic choice follows the reported sample locality (include/msda_hip.h)
+    assert lib.last_kernel("forward") in (("msda_fwd_lg3", "msda_fwd_win") if x["loc"].shape[1] >= 1024 else ("msda_fwd_lanegroup",))
     ref = msda_oracle.forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
     assert max_abs(_np(out), ref) < 1e-4
     go = torch.randn(out.shape, generator=torch.Generator().manual_seed(5)).to(dev)
@@ -274,7 +275,7 @@ def test_full_size_encoder_forward(flavour, dev, api):
     out = MSDA.ms_deform_attn_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], 64)
     assert out.shape == (2, 22223, 256)
     auto_kernel = lib.last_kernel("forward")
-    assert auto_kernel == "msda_fwd_lg3"
+    assert auto_kernel in ("msda_fwd_lg3", "msda_fwd_win")
     for other in ("msda_fwd_lanegroup", "msda_fwd_tiled_l0", "msda_fwd_lgcl", "msda_fwd_lg3", "msda_fwd_lgp", "msda_fwd_win"):   # every fast kernel
         lib.set_variant("forward", other)
         try:
@@ -300,9 +301,16 @@ def test_full_size_encoder_forward(flavour, dev, api):
     ones = ones.view(2, 22223, 8, 32)
     assert float((ones - ones[..., :1]).abs().max()) < 1e-6
     assert float(ones.min()) >= 0.0 and float(ones.max()) <= 1.0 + 1e-5
-    # (4) determinism: the forward has no atomics -> bitwise repeatable
-    again = MSDA.ms_deform_attn_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], 64)
-    assert torch.equal(out, again)
+    # (4) determinism: no forward kernel has atomics -> bitwise repeatable per kernel (the automatic choice may move
+    #     between the window and the gather kernel from one call to the next: summation order, checked above)
+    for pinned in ("msda_fwd_lg3", "msda_fwd_win"):
+        lib.set_variant("forward", pinned)
+        try:
+            a = MSDA.ms_deform_attn_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], 64)
+            b = MSDA.ms_deform_attn_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], 64)
+        finally:
+            lib.set_variant("forward", "auto")
+        assert torch.equal(a, b)
 
 
 def test_full_size_decoder_forward(dev, api):

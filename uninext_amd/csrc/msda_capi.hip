@@ -179,6 +179,8 @@ const char* msda_hip_variant_name(int which, int variant) {
   return kVariantNames[which][variant];
 }
 
+int msda_hip_forward_locality(double* far_fraction) { return msda::forward_locality(far_fraction); }
+
 const char* msda_hip_last_kernel(int which) {
   return (which < 0 || which > 1) ? "" : g_last_kernel[which].load(std::memory_order_relaxed);
 }

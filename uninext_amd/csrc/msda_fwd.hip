@@ -937,7 +937,9 @@ int launch_forward<float>(int variant, const float* value, const int64_t* shapes
   const bool tl = tiled_forward_ok(d);
   // kbench A/B (profiles/): msda_fwd_lg3 beats msda_fwd_lanegroup by 14-20 % from ~1000 queries on; the tiled and
   // lgcl kernels lose and stay opt-in
-  if (variant == kAuto) variant = lg3_ok(d) ? kLaneGroupL3 : (lg ? kLaneGroup : kGeneric);
+  // ... and the LDS-window kernel beats msda_fwd_lg3 on the encoder shape while the samples stay near their queries:
+  // win_forward_auto follows the locality the window kernel itself reported for the latest launches
+  if (variant == kAuto) variant = win_forward_auto(d) ? kWin : (lg3_ok(d) ? kLaneGroupL3 : (lg ? kLaneGroup : kGeneric));
   if (variant == kWin && !win_forward_ok(d)) variant = lg3_ok(d) ? kLaneGroupL3 : kLaneGroup;
   if (variant == kWin) {
     *kernel_name = "msda_fwd_win";

@@ -33,6 +33,8 @@
 // ceil(S / 128) workgroups per (image, head) -- at least the number of tiles of any pyramid whose level 0 holds
 // <= ~3/4 of the pixels -- and a workgroup walks tiles g, g + G, ... (one tile, or none, at the R50 shapes).
 #include <cstdlib>
+#include <cstring>
+#include <mutex>
 #include <type_traits>
 
 #include "msda_common.hpp"
@@ -41,6 +43,11 @@ namespace msda {
 namespace {
 
 constexpr int kT = 512, kWaves = kT / 64, kQuads = kT / 4;
+// auto dispatch (win_forward_auto): the window kernel is used while the last reported far fraction is at most this
+// (kbench flavours: model 0.1x -> window kernel ahead, wide / uniform -> msda_fwd_lg3 ahead; profiles/), and the
+// statistic is refreshed every kReprobe-th call otherwise
+constexpr double kFarFractionMax = 0.25;
+constexpr unsigned kReprobe = 64;
 constexpr int kTH = 8, kTW = 16;
 constexpr int kWH[4] = {14, 10, 8, 7};
 constexpr int kWW[4] = {22, 14, 10, 8};                         // even: slot parity == column parity in every row
@@ -56,6 +63,7 @@ struct Meta {
   int sum[2][4][4];                                             // [item parity] per level: sum x0, sum y0, count, unused
   int geo[4][4];                                                // per level: first column / row and width of the tile's queries
   int org[4][4];                                                // per level: window origin x, y; last near column / row
+  int stat[4];                                                  // this workgroup's far samples, live pairs, waves done, -
 };
 constexpr int kMetaOff = kZeroOff + kZeroBytes;
 constexpr int kLdsBytes = kMetaOff + ((sizeof(Meta) + 15) / 16) * 16;
@@ -98,16 +106,34 @@ struct Smp {
   uint32_t aF, aS;
 };
 
+// Locality statistic: how many in-range samples of a launch missed their tile's windows.  Accumulated in device
+// memory, moved by the last workgroup of the launch to a host-mapped report the dispatcher reads without a sync.
+// one word, in device memory while a launch runs and (with the report number in place of the ticket) in the
+// host-mapped report: far samples (bits 0..25), live (query, head) pairs (26..47), sampled workgroups done (48..63)
+struct LocalityCounters { unsigned long long packed; volatile unsigned long long* report; unsigned seq, pad; };
+constexpr int kStatPairShift = 26, kStatTicketShift = 48;
+// every 2^shift-th workgroup of a head is sampled: 1 in 16, fewer on launches of more than 65536 workgroups (the
+// fields above hold 4096 sampled workgroups of <= 192 pairs)
+__device__ LocalityCounters g_locality;     // .report is set by the host once per device (locality_state)
+__device__ __forceinline__ int stat_shift(int workgroups) {
+  int sh = 4;
+  while ((workgroups >> sh) > 4096) ++sh;
+  return sh;
+}
+
 }  // namespace
 
 // The kernel is VALU-issue bound (a wave64 VALU instruction occupies its SIMD for 4 clocks; profiles/): every
 // per-sample instruction below is counted -- hence packed fp32 math wherever two lanes of work sit side by side --
 // and short of registers (128 at 4 waves per SIMD): per-lane level constants are re-derived from the lane id in
 // every round, tile geometry and window origins are parked in LDS between rounds.
-template <int DMA_AUX>   // cache policy bits of the window DMA (0 = default, 2 = non-temporal)
-__global__ void __launch_bounds__(kT, 4)
-msda_fwd_win(const float* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
-             const float* __restrict__ loc, const float* __restrict__ attn, Dims d, float* __restrict__ out) {
+// STAT: this workgroup contributes to the locality statistic of the launch (1 workgroup in 16 does: the kernel below
+// runs one of two copies of this body, so that the other 15 keep the register allocation of the plain kernel -- with
+// the counting compiled into every workgroup the extra spills cost 5 us).
+template <int DMA_AUX, bool STAT>   // DMA_AUX: cache policy bits of the window DMA (0 = default, 2 = non-temporal)
+__device__ __forceinline__ void win_body(const float* __restrict__ value, const int64_t* __restrict__ shapes,
+                                         const int64_t* __restrict__ lsi, const float* __restrict__ loc,
+                                         const float* __restrict__ attn, const Dims& d, float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Meta& mt = *reinterpret_cast<Meta*>(smem + kMetaOff);
   const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -128,9 +154,14 @@ msda_fwd_win(const float* __restrict__ value, const int64_t* __restrict__ shapes
   const int TY = (lvH[0] + kTH - 1) / kTH, TX = (lvW[0] + kTW - 1) / kTW;
   const int ntiles = TY * TX, nitems = d.N * ntiles;       // work items of this head: (image, tile), image-major
   if (kk >= nitems) return;                                // over-provisioned part of the grid
+  if (STAT && tid == 0) {   // stat[3]: the number of sampled workgroups of the launch
+    const int per_head = min(K, nitems), sh = stat_shift(M * per_head);
+    mt.stat[3] = M * (((per_head - 1) >> sh) + 1);
+  }
   // the all-zero region, the placement sums (two sets: consecutive items alternate)
   for (int o = tid * 16; o < kZeroBytes; o += kT * 16) *reinterpret_cast<f32x4*>(smem + kZeroOff + o) = f32x4{0.f, 0.f, 0.f, 0.f};
   if (tid < 32) (&mt.sum[0][0][0])[tid] = 0;
+  if (tid >= 32 && tid < 35) mt.stat[tid - 32] = 0;
   __syncthreads();                                         // the sums are zero before any wave adds to them
 
   const uint32_t pixB = (uint32_t)M * 128u;
@@ -181,6 +212,7 @@ msda_fwd_win(const float* __restrict__ value, const int64_t* __restrict__ shapes
       e1 = __builtin_amdgcn_readfirstlane((int)qb<1>((uint32_t)cnt));
       e2 = e1 + __builtin_amdgcn_readfirstlane((int)qb<2>((uint32_t)cnt));
       nrest = e2 + __builtin_amdgcn_readfirstlane((int)qb<3>((uint32_t)cnt));
+      if (STAT && tid == 0) mt.stat[1] += nrest + (int)qb<0>((uint32_t)cnt);   // live pairs of this workgroup
       // round 0 = the level-0 queries of the tile, wave = tile row, quad = tile column (no division)
       live = pq < (int)qb<0>((uint32_t)nx) && wv < (int)qb<0>((uint32_t)(ye - ys));
       const int q = lvS[0] + ((int)qb<0>((uint32_t)ys) + wv) * lvW[0] + (int)qb<0>((uint32_t)xs) + pq;
@@ -329,6 +361,9 @@ msda_fwd_win(const float* __restrict__ value, const int64_t* __restrict__ shapes
         }
       }
 
+      // locality statistic of the launch (feeds the host's kernel choice, see win_forward_auto)
+      if (STAT && farmask) atomicAdd(&mt.stat[0], __builtin_popcount(farmask));   // per lane: no scalar state
+
       f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};   // channels at c0 and at c0 ^ 64
       if (rnd == 0) WIN_STAMP(5);                              // samples prepared
 
@@ -474,6 +509,44 @@ msda_fwd_win(const float* __restrict__ value, const int64_t* __restrict__ shapes
     }
     WIN_STAMP(9);                                              // all rounds done (wave 0)
   }
+  // ---- publish the locality count: workgroup (LDS) -> launch (ONE 64-bit L2 atomic per sampled workgroup: same-address
+  // atomics from all XCDs cost ~14 ns each, 3000 of them would double the kernel's time) -> host (the last sampled
+  // workgroup stores the totals into host-mapped memory) ----------------------------------------------------------------
+  if (STAT && lane == 0) {
+    LocalityCounters* const gstat = &g_locality;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (atomicAdd(&mt.stat[2], 1) == kWaves - 1) {             // the last wave of the workgroup
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const unsigned long long mine = (unsigned long long)(unsigned)atomicAdd(&mt.stat[0], 0) |
+                                      ((unsigned long long)(unsigned)mt.stat[1] << kStatPairShift) | (1ull << kStatTicketShift);
+      const unsigned long long now = atomicAdd(&gstat->packed, mine) + mine;
+      const unsigned expected = (unsigned)mt.stat[3];
+      if ((unsigned)(now >> kStatTicketShift) == expected) {      // the last sampled workgroup of the launch
+        atomicExch(&gstat->packed, 0ull);
+        // ONE 8-byte store into host-mapped memory: no system-scope fence (it would write the L2 back), no read over PCIe
+        const unsigned seq = gstat->seq + 1u;
+        gstat->seq = seq;
+        *gstat->report = (now & ((1ull << kStatTicketShift) - 1ull)) | ((unsigned long long)(seq & 0xffffu) << kStatTicketShift);
+      }
+    }
+  }
+}
+
+template <int DMA_AUX, bool STAT>
+__global__ void __launch_bounds__(kT, 4)
+msda_fwd_win(const float* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+             const float* __restrict__ loc, const float* __restrict__ attn, Dims d, float* __restrict__ out) {
+  if (STAT) {
+    // sampled workgroups: every 2^shift-th of a head (the same expressions as in the body)
+    const int M = d.M, kk = blockIdx.x / M, K = gridDim.x / M;
+    const int TY = ((int)shapes[0] + kTH - 1) / kTH, TX = ((int)shapes[1] + kTW - 1) / kTW;
+    const int nitems = d.N * TY * TX;
+    if ((kk & ((1 << stat_shift(M * min(K, nitems))) - 1)) == 0) {
+      win_body<DMA_AUX, true>(value, shapes, lsi, loc, attn, d, out);
+      return;
+    }
+  }
+  win_body<DMA_AUX, false>(value, shapes, lsi, loc, attn, d, out);
 }
 
 #ifdef MSDA_WIN_PROF
@@ -488,12 +561,93 @@ bool win_forward_ok(const Dims& d) {
          (int64_t)d.S * d.M * 128 < (int64_t)kOobOffset && d.N <= 65535;
 }
 
+namespace {
+
+// Per-device locality state: the counters the kernel accumulates into, the host-mapped report its last workgroup
+// writes, and the dispatcher's bookkeeping.  Everything here is advisory -- it picks a kernel, never a result.
+struct LocalityState {
+  volatile unsigned long long* report = nullptr;   // pinned host memory, mapped into the device: the latest report
+  unsigned long long* report_dev = nullptr;        // the device's address of `report`
+  unsigned reports = 0, last_seq = 0;              // reports seen by forward_locality (the word carries 16 bits of it)
+  std::atomic<unsigned> since_probe{0};     // auto-dispatched calls on the other kernel since the last window launch
+};
+constexpr int kMaxDevices = 64;
+LocalityState g_loc[kMaxDevices];
+std::atomic<int> g_loc_ready[kMaxDevices];
+std::mutex g_loc_mutex;
+
+LocalityState* locality_state() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+  if (g_loc_ready[dev].load(std::memory_order_acquire) == 1) return &g_loc[dev];
+  std::lock_guard<std::mutex> lock(g_loc_mutex);
+  if (g_loc_ready[dev].load(std::memory_order_relaxed) == 1) return &g_loc[dev];
+  if (g_loc_ready[dev].load(std::memory_order_relaxed) == -1) return nullptr;
+  LocalityState& st = g_loc[dev];
+  void* rp = nullptr;
+  LocalityCounters init{};
+  init.packed = 0;
+  init.seq = 0;
+  if (hipHostMalloc(&rp, sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer(reinterpret_cast<void**>(&st.report_dev), rp, 0) != hipSuccess ||
+      (init.report = st.report_dev, init.pad = 0, hipMemcpyToSymbol(HIP_SYMBOL(g_locality), &init, sizeof(init), 0, hipMemcpyHostToDevice)) != hipSuccess) {
+    (void)hipGetLastError();
+    g_loc_ready[dev].store(-1, std::memory_order_relaxed);
+    return nullptr;
+  }
+  st.report = static_cast<volatile unsigned long long*>(rp);
+  *st.report = 0ull;
+  g_loc_ready[dev].store(1, std::memory_order_release);
+  return &st;
+}
+
+}  // namespace
+
+int forward_locality(double* far_fraction) {
+  LocalityState* st = locality_state();
+  if (!st) return 0;
+  const unsigned long long w = *st->report;
+  const unsigned long long f = w & ((1ull << kStatPairShift) - 1ull);
+  const unsigned long long n = 16ull * ((w >> kStatPairShift) & ((1ull << (kStatTicketShift - kStatPairShift)) - 1ull));
+  if (far_fraction) *far_fraction = n ? (double)f / (double)n : 0.0;
+  const unsigned seq = (unsigned)(w >> kStatTicketShift);
+  {  // widen the 16-bit report number (advisory; a racing reader may count a report twice)
+    std::lock_guard<std::mutex> lock(g_loc_mutex);
+    st->reports += (seq - st->last_seq) & 0xffffu;
+    st->last_seq = seq;
+    return (int)st->reports;
+  }
+}
+
+// auto dispatch of the encoder shape: window kernel or msda_fwd_lg3?  The window kernel wins while the samples of a
+// tile stay near it and loses (up to 1.7x) when they do not, and only the locations know which.  Every launch of the
+// window kernel reports the far fraction of its own inputs; the next calls follow the latest report, and while they
+// run the other kernel every kReprobe-th call goes through the window kernel again to refresh it.
+bool win_forward_auto(const Dims& d) {
+  static const int mode = [] { const char* e = std::getenv("MSDA_HIP_FWD_ADAPTIVE"); return e ? std::atoi(e) : 1; }();
+  if (mode == 0 || !win_forward_ok(d)) return false;
+  LocalityState* st = locality_state();
+  if (!st) return false;
+  double far = 0.0;
+  const int seq = forward_locality(&far);
+  if (seq == 0 || far <= kFarFractionMax) { st->since_probe.store(0, std::memory_order_relaxed); return true; }
+  if (st->since_probe.fetch_add(1, std::memory_order_relaxed) + 1 >= kReprobe) {
+    st->since_probe.store(0, std::memory_order_relaxed);
+    return true;
+  }
+  return false;
+}
+
 int launch_forward_win(const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc, const float* attn,
                        const Dims& d, float* out, hipStream_t stream) {
   static const bool nt = std::getenv("MSDA_WIN_NT") && std::getenv("MSDA_WIN_NT")[0] == '1';   // A/B switch
-  static std::atomic<uint64_t> lds_opted_in[2] = {{0}, {0}};
-  const void* fn = nt ? reinterpret_cast<const void*>(msda_fwd_win<2>) : reinterpret_cast<const void*>(msda_fwd_win<0>);
-  if (int rc = ensure_dynamic_lds(fn, kLdsBytes, lds_opted_in[nt ? 1 : 0])) return rc;
+  static std::atomic<uint64_t> lds_opted_in[3] = {{0}, {0}, {0}};
+  static const bool stat = !(std::getenv("MSDA_WIN_STAT") && std::getenv("MSDA_WIN_STAT")[0] == '0');   // A/B switch
+  const auto kern = nt ? msda_fwd_win<2, true> : (stat ? msda_fwd_win<0, true> : msda_fwd_win<0, false>);
+  const void* fn = reinterpret_cast<const void*>(kern);
+  if (int rc = ensure_dynamic_lds(fn, kLdsBytes, lds_opted_in[nt ? 1 : (stat ? 0 : 2)])) return rc;
+  LocalityState* st = locality_state();
+  if (!st) return (int)hipErrorOutOfMemory;
   // Workgroups per head.  Default: one work item per workgroup -- the host only knows S, so ceil(S / 128) per image,
   // at least the tile count of any pyramid whose level 0 holds <= ~3/4 of the pixels; the surplus exits at once and the
   // dispatcher staggers the rest, which keeps the memory / LDS / VALU phases of neighbouring workgroups out of step.
@@ -504,10 +658,7 @@ int launch_forward_win(const float* value, const int64_t* shapes, const int64_t*
   int K = persist ? (2 * 256) / d.M : d.N * ((d.S + 127) / 128);
   if (K < 1) K = 1;
   const dim3 grid((unsigned)(d.M * K), 1u);
-  if (nt)
-    hipLaunchKernelGGL(msda_fwd_win<2>, grid, dim3(kT), kLdsBytes, stream, value, shapes, lsi, loc, attn, d, out);
-  else
-    hipLaunchKernelGGL(msda_fwd_win<0>, grid, dim3(kT), kLdsBytes, stream, value, shapes, lsi, loc, attn, d, out);
+  hipLaunchKernelGGL(kern, grid, dim3(kT), kLdsBytes, stream, value, shapes, lsi, loc, attn, d, out);
   return (int)hipGetLastError();
 }
 
