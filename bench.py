@@ -26,8 +26,9 @@ Extra objects on the JSON line (all measured in this run, after the timed region
                 sources (sha256 of uninext_amd/csrc); null otherwise.
   flavours      encoder-forward launch time (us) on the two other location distributions: `uniform`
                 (ops/test.py:34, no locality) and `wide` (model-like with sigma = 6 px offsets).
-  window_kernel the opt-in LDS-window forward kernel (msda_fwd_win) on the headline inputs and on the two other
-                flavours -- not what `auto` runs: it wins only when the samples stay near their query.
+  forward_kernels  both encoder-forward kernels pinned (msda_fwd_win: LDS windows; msda_fwd_lg3: gather), launch time
+                on the three flavours, and the far fraction the window kernel reports for each.  The timed region
+                runs variant 0, which follows that report (include/msda_hip.h: window kernel while <= 0.25).
   backward      BASELINE configs[4] (training step): the encoder-call and the decoder-call backward launches
                 (grad_value pre-zeroed outside the events): kernel, launch_us, algorithmic bytes
                 (N*(2048*S + 4096*Lq)), achieved GB/s, fraction of 8 TB/s, traffic (as above, or null).
@@ -186,6 +187,7 @@ def measure_flavours(rank, reps=12):
         xs = [workloads.make_inputs("encoder", batch=BATCH, seed=100 * rank + 70 + i, **flavour_kwargs(fl)) for i in range(3)]
         for x in xs:
             call(x)
+            torch.cuda.synchronize()      # variant 0 follows the locality report of the previous launch: let it land
         k = [0]
 
         def one():
@@ -196,39 +198,41 @@ def measure_flavours(rank, reps=12):
     return out
 
 
-def measure_window_kernel(enc, reps=12):
-    """The opt-in LDS-window forward (msda_fwd_win, MSDA_HIP_FWD_VARIANT=9) on the headline inputs: faster than the
-    default when the samples of a tile stay near it (this flavour), slower when they do not -- see `flavours` -- and the
-    host cannot tell which without looking at the locations, so `auto` does not take it (profiles/r02_window_forward_experiments.txt)."""
+def measure_forward_kernels(enc, reps=12):
+    """Both encoder-forward kernels pinned, on the headline inputs and on the two other flavours, and the sample locality
+    the window kernel reports for them.  Variant 0 (`auto`, what the timed region runs) follows that report: window
+    kernel while the far fraction is <= 0.25, gather kernel otherwise (include/msda_hip.h)."""
     out = {}
-    _lib.set_variant("forward", "msda_fwd_win")
+    S = enc[0]["value"].shape[1]
+    alg = workloads.algorithmic_bytes_forward(BATCH, S, S)
+    sets = {"model": enc[:3]}
+    for fl in ("uniform", "wide"):
+        sets[fl] = [workloads.make_inputs("encoder", batch=BATCH, seed=70 + i, **flavour_kwargs(fl)) for i in range(2)]
     try:
-        for x in enc[:3]:
-            call(x)
-        k = [0]
+        for name in ("msda_fwd_win", "msda_fwd_lg3"):
+            _lib.set_variant("forward", name)
+            rec = {}
+            for fl, xs in sets.items():
+                for x in xs:
+                    call(x)
+                k = [0]
 
-        def one():
-            k[0] += 1
-            call(enc[k[0] % len(enc)])
-        us = time_events(one, reps)
-        kern = _lib.last_kernel("forward")
-        S = enc[0]["value"].shape[1]
-        alg = workloads.algorithmic_bytes_forward(BATCH, S, S)
-        out = {"kernel": kern, "launch_us": us, "achieved": alg / us / 1e3, "unit": "GB/s", "frac": alg / us / 1e3 / HBM_PEAK_GBS,
-               "traffic": committed_traffic(kern, "forward_encoder_window"), "selected_by": "msda_hip_set_variant(0, 9)"}
-        for fl in ("uniform", "wide"):
-            xs = [workloads.make_inputs("encoder", batch=BATCH, seed=70 + i, **flavour_kwargs(fl)) for i in range(2)]
-            for x in xs:
-                call(x)
-            j = [0]
-
-            def other():
-                j[0] += 1
-                call(xs[j[0] % len(xs)])
-            out[fl + "_launch_us"] = time_events(other, 6)
-            del xs
+                def one():
+                    k[0] += 1
+                    call(xs[k[0] % len(xs)])
+                us = time_events(one, reps if fl == "model" else 6)
+                rec[fl + "_launch_us"] = us
+                if name == "msda_fwd_win":
+                    torch.cuda.synchronize()
+                    out.setdefault("far_fraction", {})[fl] = _lib.forward_locality()[1]
+            rec["achieved"] = alg / rec["model_launch_us"] / 1e3
+            rec["frac"] = rec["achieved"] / HBM_PEAK_GBS
+            rec["traffic"] = committed_traffic(name, "forward_encoder") or committed_traffic(name, "forward_encoder_lg3")
+            out[name] = rec
     finally:
         _lib.set_variant("forward", "auto")
+        call(enc[0])                      # leave the locality report on the headline flavour
+        torch.cuda.synchronize()
     return out
 
 
@@ -430,7 +434,7 @@ def main():
         if "flavours" in want:
             extras["flavours"] = measure_flavours(rank)
             if args.flavour == "model":
-                extras["window_kernel"] = measure_window_kernel(enc)
+                extras["forward_kernels"] = measure_forward_kernels(enc)
         if "backward" in want:
             extras["backward"] = measure_backward(enc, dec)
         if "train" in want:

@@ -1,3 +1,7 @@
+#!/usr/bin/env python
+"""Automatic forward-kernel choice on the GPU box (include/msda_hip.h, msda_hip_forward_locality): per location
+flavour the launch time of the window kernel, of the gather kernel and of variant 0, the far fraction the window
+kernel reports, and the kernels variant 0 runs while the inputs change flavour."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""HBM traffic per launch of the three contract kernels, by the recipe of MI355X_MICROARCH.md (HBM section):
+"""HBM traffic per launch of the contract kernels, by the recipe of MI355X_MICROARCH.md (HBM section):
 separate `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes (the TCC slots do not fit both), FETCH_SIZE
 doubled (gfx950 tallies the 128-byte read requests of wide loads as 64 B), per launch.
 
@@ -7,8 +7,8 @@ doubled (gfx950 tallies the 128-byte read requests of wide loads as 64 B), per l
 
 Runs on the GPU box (from the repository root; rocprofv3 output goes to gpurun_out/traffic_prof).  The parent
 starts `rocprofv3 ... -- python tools/measure_traffic.py --child` once per counter set; the child launches, in this
-order and separated by a marker kernel, `reps` encoder forward calls (default kernel), `reps` with the opt-in window
-kernel, `reps` encoder backward calls and `reps` decoder backward calls (BASELINE configs[1] / configs[4] shapes, model-like locations, rotating input sets).
+order and separated by a marker kernel, `reps` encoder forward calls (variant 0: the window kernel on these inputs), `reps` with the gather
+kernel pinned, `reps` encoder backward calls and `reps` decoder backward calls (BASELINE configs[1] / configs[4] shapes, model-like locations, rotating input sets).
 The parent splits the dispatch-ordered counter rows into one run of msda:: kernels per call and writes
 
     {"source_hash": <bench.kernel_source_hash()>, "git": <HEAD>, "entries": {"forward_encoder": {"kernel": ...,
@@ -25,7 +25,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-PHASES = ("forward_encoder", "forward_encoder_window", "backward_encoder", "backward_decoder")
+PHASES = ("forward_encoder", "forward_encoder_lg3", "backward_encoder", "backward_decoder")
 SQ_COUNTERS = ["SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS",
                "SQ_INSTS_VALU", "SQ_INSTS_VMEM_RD", "SQ_LDS_BANK_CONFLICT"]
 
@@ -52,7 +52,7 @@ def child(reps):
             b[1].zero_()
             marker.add_(1.0)
             if phase < 2:
-                _lib.set_variant("forward", "msda_fwd_win" if phase == 1 else "auto")
+                _lib.set_variant("forward", "msda_fwd_lg3" if phase == 1 else "auto")
                 bench.call(x)
                 _lib.set_variant("forward", "auto")
             else:
@@ -138,7 +138,7 @@ def main():
     _, write = profile(["WRITE_SIZE"], args.reps, args.workdir, "write")
     S = sum(h * w for h, w in workloads.R50_LEVELS_INFER)
     alg = {"forward_encoder": workloads.algorithmic_bytes_forward(2, S, S),
-           "forward_encoder_window": workloads.algorithmic_bytes_forward(2, S, S),
+           "forward_encoder_lg3": workloads.algorithmic_bytes_forward(2, S, S),
            "backward_encoder": workloads.algorithmic_bytes_backward(2, S, S),
            "backward_decoder": workloads.algorithmic_bytes_backward(2, S, 900)}
     try:
