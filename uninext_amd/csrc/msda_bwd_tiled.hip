@@ -420,14 +420,24 @@ msda_bwd_tiled(const float* __restrict__ grad_out, const float* __restrict__ val
             const float pa = pa2.x + pa2.y, pwx = pw2.x + pw2.y, phy = ph2.x + ph2.y;
             // near samples: accumulate into the LDS window; dead corners and far samples go to the pair's sink slot
             const v2f wh = v2f{hh, lh} * hw, wl = v2f{hh, lh} * lw;      // (w1, w3), (w2, w4)
+#ifdef MSDA_BWD_NOCONF   // timing experiment only (wrong results): every ds_add conflict-free by construction
+            const uint32_t a1 = smem_base + (uint32_t)lane * 4u, a2 = a1 + 1024u, a3 = a1 + 2048u, a4 = a1 + 3072u;
+            asm volatile("" :: "v"(cur.ak[0]), "v"(cur.ak[1]), "v"(cur.ak[2]), "v"(cur.ak[3]));
+#else
             const uint32_t a1 = cur.ak[0] + lane_off, a2 = cur.ak[1] + lane_off, a3 = cur.ak[2] + lane_off, a4 = cur.ak[3] + lane_off;
+#endif
 #pragma unroll
             for (int cp = 0; cp < 2; ++cp) {
               const v2f g1 = tgs[cp] * wh.x, g2 = tgs[cp] * wl.x, g3 = tgs[cp] * wh.y, g4 = tgs[cp] * wl.y;
-              lds_add(a1 + 8u * cp, cvt_rn_i32(g1.x)); lds_add(a1 + 8u * cp + 4u, cvt_rn_i32(g1.y));
-              lds_add(a2 + 8u * cp, cvt_rn_i32(g2.x)); lds_add(a2 + 8u * cp + 4u, cvt_rn_i32(g2.y));
-              lds_add(a3 + 8u * cp, cvt_rn_i32(g3.x)); lds_add(a3 + 8u * cp + 4u, cvt_rn_i32(g3.y));
-              lds_add(a4 + 8u * cp, cvt_rn_i32(g4.x)); lds_add(a4 + 8u * cp + 4u, cvt_rn_i32(g4.y));
+#ifdef MSDA_BWD_NOCONF
+              constexpr uint32_t kC0 = 256u, kC1 = 512u;
+#else
+              constexpr uint32_t kC0 = 8u, kC1 = 4u;
+#endif
+              lds_add(a1 + kC0 * cp, cvt_rn_i32(g1.x)); lds_add(a1 + kC0 * cp + kC1, cvt_rn_i32(g1.y));
+              lds_add(a2 + kC0 * cp, cvt_rn_i32(g2.x)); lds_add(a2 + kC0 * cp + kC1, cvt_rn_i32(g2.y));
+              lds_add(a3 + kC0 * cp, cvt_rn_i32(g3.x)); lds_add(a3 + kC0 * cp + kC1, cvt_rn_i32(g3.y));
+              lds_add(a4 + kC0 * cp, cvt_rn_i32(g4.x)); lds_add(a4 + kC0 * cp + kC1, cvt_rn_i32(g4.y));
             }
             far_any |= __ballot((flags & 16u) != 0u);
             const float ra = group8_sum(pa);
