@@ -431,16 +431,26 @@ def main():
     extras = {}
     want = set(args.extras_only.split(",")) if args.extras_only else {"flavours", "backward", "train", "ddp"}
     if not args.no_extras:   # every rank takes part (collectives inside), rank 0 reports
+        def extra(key, fn):      # an extra that fails must not take the contract line with it
+            try:
+                extras[key] = fn()
+            except Exception as e:  # noqa: BLE001
+                extras[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+                try:
+                    _lib.set_variant("forward", "auto")
+                    _lib.set_variant("backward", "auto")
+                except Exception:  # noqa: BLE001
+                    pass
         if "flavours" in want:
-            extras["flavours"] = measure_flavours(rank)
+            extra("flavours", lambda: measure_flavours(rank))
             if args.flavour == "model":
-                extras["forward_kernels"] = measure_forward_kernels(enc)
+                extra("forward_kernels", lambda: measure_forward_kernels(enc))
         if "backward" in want:
-            extras["backward"] = measure_backward(enc, dec)
+            extra("backward", lambda: measure_backward(enc, dec))
         if "train" in want:
-            extras["train_step"] = measure_train_step(enc, dec, world)
+            extra("train_step", lambda: measure_train_step(enc, dec, world))
         if "ddp" in want and world > 1:
-            extras["ddp"] = measure_ddp(enc, dec, world)
+            extra("ddp", lambda: measure_ddp(enc, dec, world))
 
     if rank == 0:
         enc_ms = sum(a.elapsed_time(b) for a, b in events) / (args.steps * ENC_LAYERS)  # per encoder launch

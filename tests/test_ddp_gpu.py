@@ -106,3 +106,38 @@ def test_ddp_two_ranks_match_single_process():
     # both ranks hold identical (averaged) parameter gradients
     for n in res[0][1]:
         assert np.array_equal(res[0][1][n], res[1][1][n]), n
+
+
+def _bench_ddp_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import bench
+    bench.DDP_GRAD_BYTES = 2 * bench.DDP_BUCKET_BYTES + 1          # three buckets: keep the gloo round trips short
+    enc, dec = bench.build_inputs("model", rank)
+    res = bench.measure_ddp(enc[:1], dec[:1], world, reps=1)
+    st = bench.measure_train_step(enc[:1], dec[:1], world, reps=1)
+    q.put((rank, res, st))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_ddp_leg_runs_on_two_ranks():
+    """bench.py's config-5 legs (`train_step`, `ddp`) with world_size 2: the driver runs them over RCCL on 2-8 GPUs;
+    here the same code runs over gloo on one GPU so that a broken leg shows up before the scaling run."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_bench_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=900) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, ddp, st in res:
+        assert ddp["buckets"] == 3 and ddp["allreduce_ms"] > 0 and ddp["overlapped_ms"] > 0 and ddp["op_fwd_bwd_ms"] > 0
+        assert st["ms_per_step"] > 0
+    assert res[0][1]["allreduce_ms"] == res[1][1]["allreduce_ms"]          # MAX over ranks on every rank
