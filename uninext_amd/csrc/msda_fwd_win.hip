@@ -101,6 +101,12 @@ __device__ __forceinline__ int dppi(int v) { return __builtin_amdgcn_update_dpp(
 // One prepared NEAR sample in the preparing lane's registers: corner weights (first-top, second-top), (first-bottom,
 // second-bottom) and the LDS byte addresses of the first / second pixel of the top row -- "first" is the pixel whose
 // slot parity this quad reads first.  Dead and far samples carry zero weights and point at the zero region.
+__device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c) {   // (a & 0xffffff) * (b & 0xffffff) + c
+  uint32_t r;
+  asm volatile("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));   // volatile: stays out of branches
+  return r;
+}
+
 struct Smp {
   v2f wT, wB;
   uint32_t aF, aS;
@@ -303,30 +309,35 @@ __device__ __forceinline__ void win_body(const float* __restrict__ value, const 
           ogx[3] = __builtin_amdgcn_readfirstlane((int)qb<3>((uint32_t)myOx)); ogy[3] = __builtin_amdgcn_readfirstlane((int)qb<3>((uint32_t)myOy));
           const uint32_t chunk = (uint32_t)(lane & 7) * 16u;
           const int sub = lane >> 3;
-          int cl = -1, r = 0, c = 0;                            // level of the previous chunk, this lane's window row / column
-          for (int i = wv; i < kSlots / 8; i += kWaves) {        // i, and with it the level, is wave-uniform
-            const int sl = (i >= kBase[1] / 8 ? 1 : 0) + (i >= kBase[2] / 8 ? 1 : 0) + (i >= kBase[3] / 8 ? 1 : 0);
-            const int ww = sl == 0 ? kWW[0] : sl == 1 ? kWW[1] : sl == 2 ? kWW[2] : kWW[3];
-            if (sl != cl) {                                      // first chunk of a level for this wave (uniform branch)
-              const int rel = 8 * i + sub - (sl == 0 ? kBase[0] : sl == 1 ? kBase[1] : sl == 2 ? kBase[2] : kBase[3]);
-              r = (int)(((float)rel + 0.5f) * (sl == 0 ? 1.f / kWW[0] : sl == 1 ? 1.f / kWW[1] : sl == 2 ? 1.f / kWW[2] : 1.f / kWW[3]));
-              c = rel - r * ww;
-              cl = sl;
-            } else {                                             // 8 waves x 8 slots further in the same window
-              c += 64 % ww; r += 64 / ww;
-              if (c >= ww) { c -= ww; r += 1; }
+          // per level with compile-time window geometry: chunk i (a multiple of the wave count apart) of level LV covers
+          // slots 8 (i - C0) + sub of its window; the (row, column) of a lane advances by 64 slots per step
+          auto stage_level = [&](auto ltag) __attribute__((always_inline)) {
+            constexpr int LV = decltype(ltag)::value;
+            constexpr int WW = kWW[LV], C0 = kBase[LV] / 8, C1 = kBase[LV + 1] / 8;
+            const int Hs = lvH[LV], Ws = lvW[LV], xS = ogx[LV] + lvS[LV], oy = ogy[LV], ox = ogx[LV];
+            int i = C0 + ((wv - C0) & (kWaves - 1));             // this wave's first chunk of the level
+            int subv = sub;
+            asm volatile("" : "+v"(subv));                    // opaque: the level's start is computed HERE, not ahead of the
+            const int rel = 8 * (i - C0) + subv;                //         previous level's loop (that cost a spill and a vmcnt(0))
+            int r = (int)(((float)rel + 0.5f) * (1.f / WW)), c = rel - r * WW;
+            for (; i < C1; i += kWaves) {
+              const int y = oy + r;
+              const bool inside = (unsigned)y < (unsigned)Hs && (unsigned)(ox + c) < (unsigned)Ws;
+              // pixel index < 2^24 and pixel pitch M * 128 < 2^24 by win_forward_ok: two full-rate 24-bit multiply-adds
+              // (left to the compiler, __mul24 comes back as quarter-rate v_mul_lo_u32)
+              const uint32_t pix = mad_u24((uint32_t)y, (uint32_t)Ws, (uint32_t)(xS + c));
+              const uint32_t in_off = mad_u24(pix, pixB, chunk);
+              const uint32_t off = inside ? in_off : kOobOffset;
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(vsrc, (__attribute__((address_space(3))) void*)(smem + i * 1024), 16,
+                                                       off, hoff, 0, DMA_AUX);
+              c += 64 % WW; r += 64 / WW;
+              if (c >= WW) { c -= WW; r += 1; }
             }
-            const int Hs = sl == 0 ? lvH[0] : sl == 1 ? lvH[1] : sl == 2 ? lvH[2] : lvH[3];
-            const int Ws = sl == 0 ? lvW[0] : sl == 1 ? lvW[1] : sl == 2 ? lvW[2] : lvW[3];
-            const int Ss = sl == 0 ? lvS[0] : sl == 1 ? lvS[1] : sl == 2 ? lvS[2] : lvS[3];
-            const int y = (sl == 0 ? ogy[0] : sl == 1 ? ogy[1] : sl == 2 ? ogy[2] : ogy[3]) + r;
-            const int x = (sl == 0 ? ogx[0] : sl == 1 ? ogx[1] : sl == 2 ? ogx[2] : ogx[3]) + c;
-            const bool inside = (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws;
-            const uint32_t pix = (uint32_t)__mul24(__mul24(y, Ws) + x + Ss, M);   // < 2^24 by win_forward_ok
-            const uint32_t off = inside ? (pix << 7) + chunk : kOobOffset;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(vsrc, (__attribute__((address_space(3))) void*)(smem + i * 1024), 16,
-                                                     off, hoff, 0, DMA_AUX);
-          }
+          };
+          stage_level(std::integral_constant<int, 0>{});
+          stage_level(std::integral_constant<int, 1>{});
+          stage_level(std::integral_constant<int, 2>{});
+          stage_level(std::integral_constant<int, 3>{});
         }
         WIN_STAMP(4);                                          // window DMA issued
       } else {
