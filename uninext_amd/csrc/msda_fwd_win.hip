@@ -63,6 +63,7 @@ struct Meta {
   int sum[2][4][4];                                             // [item parity] per level: sum x0, sum y0, count, unused
   int geo[4][4];                                                // per level: first column / row and width of the tile's queries
   int org[4][4];                                                // per level: window origin x, y; last near column / row
+  int lvl[4][8];                                                // per level: H, W, first pixel, window rows, window columns, window byte offset
   int stat[4];                                                  // this workgroup's far samples, live pairs, waves done, -
 };
 constexpr int kMetaOff = kZeroOff + kZeroBytes;
@@ -167,6 +168,17 @@ __device__ __forceinline__ void win_body(const float* __restrict__ value, const 
   // the all-zero region, the placement sums (two sets: consecutive items alternate)
   for (int o = tid * 16; o < kZeroBytes; o += kT * 16) *reinterpret_cast<f32x4*>(smem + kZeroOff + o) = f32x4{0.f, 0.f, 0.f, 0.f};
   if (tid < 32) (&mt.sum[0][0][0])[tid] = 0;
+  // per-level constants as an LDS table: a lane fetches its level's row with two reads -- selecting them by the lane's level
+  // from scalar registers (k == 0 ? .. : k == 1 ? ..) compiles into trees of exec-masked branches, in every round
+  if (tid >= 64 && tid < 68) {
+    const int l = tid - 64;
+    const int4 a = make_int4(l == 0 ? lvH[0] : l == 1 ? lvH[1] : l == 2 ? lvH[2] : lvH[3], l == 0 ? lvW[0] : l == 1 ? lvW[1] : l == 2 ? lvW[2] : lvW[3],
+                             l == 0 ? lvS[0] : l == 1 ? lvS[1] : l == 2 ? lvS[2] : lvS[3], l == 0 ? kWH[0] : l == 1 ? kWH[1] : l == 2 ? kWH[2] : kWH[3]);
+    const int4 b = make_int4(l == 0 ? kWW[0] : l == 1 ? kWW[1] : l == 2 ? kWW[2] : kWW[3],
+                             128 * (l == 0 ? kBase[0] : l == 1 ? kBase[1] : l == 2 ? kBase[2] : kBase[3]), 0, 0);
+    *reinterpret_cast<int4*>(&mt.lvl[l][0]) = a;
+    *reinterpret_cast<int4*>(&mt.lvl[l][4]) = b;
+  }
   if (tid >= 32 && tid < 35) mt.stat[tid - 32] = 0;
   __syncthreads();                                         // the sums are zero before any wave adds to them
 
@@ -204,8 +216,8 @@ __device__ __forceinline__ void win_body(const float* __restrict__ value, const 
       // tile t.  Evaluated in float: any monotone f with f(0) = 0 gives an exact partition as long as every workgroup
       // evaluates the same expression, which is all that correctness needs.
       const int kq = lane & 3;
-      const int gW = kq == 0 ? lvW[0] : kq == 1 ? lvW[1] : kq == 2 ? lvW[2] : lvW[3];
-      const int gH = kq == 0 ? lvH[0] : kq == 1 ? lvH[1] : kq == 2 ? lvH[2] : lvH[3];
+      const int2 gHW = *reinterpret_cast<const int2*>(&mt.lvl[kq][0]);
+      const int gW = gHW.y, gH = gHW.x;
       const float fxs = (float)(kTW * gW) / (float)lvW[0], fys = (float)(kTH * gH) / (float)lvH[0];
       const int tile_ = item - b * ntiles;
       const int ty = (int)(((float)tile_ + 0.5f) / (float)TX), tx = tile_ - ty * TX;
@@ -237,10 +249,9 @@ __device__ __forceinline__ void win_body(const float* __restrict__ value, const 
       // this lane's channels: the 16-byte pieces k and k + 4 of a pixel, i.e. a quad reads / writes 64 contiguous bytes
       // per instruction; c0 = the piece read first, c0 ^ 64 the other
       const uint32_t c0 = (uint32_t)(16 * k + 64 * cls_a);
-      const int myH = k == 0 ? lvH[0] : k == 1 ? lvH[1] : k == 2 ? lvH[2] : lvH[3];
-      const int myW = k == 0 ? lvW[0] : k == 1 ? lvW[1] : k == 2 ? lvW[2] : lvW[3];
-      const int myWH = k == 0 ? kWH[0] : k == 1 ? kWH[1] : k == 2 ? kWH[2] : kWH[3];
-      const int myWW = k == 0 ? kWW[0] : k == 1 ? kWW[1] : k == 2 ? kWW[2] : kWW[3];
+      const int4 lv4 = *reinterpret_cast<const int4*>(&mt.lvl[k][0]);
+      const int2 lv2 = *reinterpret_cast<const int2*>(&mt.lvl[k][4]);
+      const int myH = lv4.x, myW = lv4.y, myS = lv4.z, myWH = lv4.w, myWW = lv2.x;
       const v2f fWH = {(float)myW, (float)myH};
 
       // ---- sample coordinates (the reference's arithmetic, cuh:282-288 and :38-46) ----------------------------------
@@ -300,56 +311,63 @@ __device__ __forceinline__ void win_body(const float* __restrict__ value, const 
           rymax = (uint32_t)(min(myOy + myWH - 2, myH - 1) - myOy);
           if (tid < 4) *reinterpret_cast<int4*>(&mt.org[k][0]) = make_int4(myOx, myOy, (int)cxmax, (int)rymax);   // for the later rounds
         }
-        // ---- stage the four windows: LDS-DMA, one instruction = 8 consecutive slots (1 KB) of ONE level per wave -------
-        {
-          int ogx[4], ogy[4];
-          ogx[0] = __builtin_amdgcn_readfirstlane((int)qb<0>((uint32_t)myOx)); ogy[0] = __builtin_amdgcn_readfirstlane((int)qb<0>((uint32_t)myOy));
-          ogx[1] = __builtin_amdgcn_readfirstlane((int)qb<1>((uint32_t)myOx)); ogy[1] = __builtin_amdgcn_readfirstlane((int)qb<1>((uint32_t)myOy));
-          ogx[2] = __builtin_amdgcn_readfirstlane((int)qb<2>((uint32_t)myOx)); ogy[2] = __builtin_amdgcn_readfirstlane((int)qb<2>((uint32_t)myOy));
-          ogx[3] = __builtin_amdgcn_readfirstlane((int)qb<3>((uint32_t)myOx)); ogy[3] = __builtin_amdgcn_readfirstlane((int)qb<3>((uint32_t)myOy));
-          const uint32_t chunk = (uint32_t)(lane & 7) * 16u;
-          const int sub = lane >> 3;
-          // per level with compile-time window geometry: chunk i (a multiple of the wave count apart) of level LV covers
-          // slots 8 (i - C0) + sub of its window; the (row, column) of a lane advances by 64 slots per step
-          auto stage_level = [&](auto ltag) __attribute__((always_inline)) {
-            constexpr int LV = decltype(ltag)::value;
-            constexpr int WW = kWW[LV], C0 = kBase[LV] / 8, C1 = kBase[LV + 1] / 8;
-            const int Hs = lvH[LV], Ws = lvW[LV], xS = ogx[LV] + lvS[LV], oy = ogy[LV], ox = ogx[LV];
-            int i = C0 + ((wv - C0) & (kWaves - 1));             // this wave's first chunk of the level
-            int subv = sub;
-            asm volatile("" : "+v"(subv));                    // opaque: the level's start is computed HERE, not ahead of the
-            const int rel = 8 * (i - C0) + subv;                //         previous level's loop (that cost a spill and a vmcnt(0))
-            int r = (int)(((float)rel + 0.5f) * (1.f / WW)), c = rel - r * WW;
-            for (; i < C1; i += kWaves) {
-              const int y = oy + r;
-              const bool inside = (unsigned)y < (unsigned)Hs && (unsigned)(ox + c) < (unsigned)Ws;
-              // pixel index < 2^24 and pixel pitch M * 128 < 2^24 by win_forward_ok: two full-rate 24-bit multiply-adds
-              // (left to the compiler, __mul24 comes back as quarter-rate v_mul_lo_u32)
-              const uint32_t pix = mad_u24((uint32_t)y, (uint32_t)Ws, (uint32_t)(xS + c));
-              const uint32_t in_off = mad_u24(pix, pixB, chunk);
-              const uint32_t off = inside ? in_off : kOobOffset;
-              __builtin_amdgcn_raw_ptr_buffer_load_lds(vsrc, (__attribute__((address_space(3))) void*)(smem + i * 1024), 16,
-                                                       off, hoff, 0, DMA_AUX);
-              c += 64 % WW; r += 64 / WW;
-              if (c >= WW) { c -= WW; r += 1; }
-            }
-          };
-          stage_level(std::integral_constant<int, 0>{});
-          stage_level(std::integral_constant<int, 1>{});
-          stage_level(std::integral_constant<int, 2>{});
-          stage_level(std::integral_constant<int, 3>{});
-        }
-        WIN_STAMP(4);                                          // window DMA issued
       } else {
         const int4 og = *reinterpret_cast<const int4*>(&mt.org[k][0]);
         myOx = og.x; myOy = og.y; cxmax = (uint32_t)og.z; rymax = (uint32_t)og.w;
       }
 
+      // ---- stage the four windows: LDS-DMA, one instruction = 8 consecutive slots (1 KB) of ONE level per wave.  Straight-line
+      // code with the same number of instructions in every wave (a wave without a chunk left in a level issues an
+      // out-of-range one into the all-zero region, which costs no memory access), so that loads issued BEFORE it can be
+      // waited for with an exact vmcnt while the windows are still in flight -------------------------------------------
+      auto stage_windows = [&]() __attribute__((always_inline)) {
+        int ogx[4], ogy[4];
+        ogx[0] = __builtin_amdgcn_readfirstlane((int)qb<0>((uint32_t)myOx)); ogy[0] = __builtin_amdgcn_readfirstlane((int)qb<0>((uint32_t)myOy));
+        ogx[1] = __builtin_amdgcn_readfirstlane((int)qb<1>((uint32_t)myOx)); ogy[1] = __builtin_amdgcn_readfirstlane((int)qb<1>((uint32_t)myOy));
+        ogx[2] = __builtin_amdgcn_readfirstlane((int)qb<2>((uint32_t)myOx)); ogy[2] = __builtin_amdgcn_readfirstlane((int)qb<2>((uint32_t)myOy));
+        ogx[3] = __builtin_amdgcn_readfirstlane((int)qb<3>((uint32_t)myOx)); ogy[3] = __builtin_amdgcn_readfirstlane((int)qb<3>((uint32_t)myOy));
+        const uint32_t chunk = (uint32_t)(lane & 7) * 16u;
+        const int sub = lane >> 3;
+        auto stage_level = [&](auto ltag) __attribute__((always_inline)) {
+          constexpr int LV = decltype(ltag)::value;
+          constexpr int WW = kWW[LV], C0 = kBase[LV] / 8, C1 = kBase[LV + 1] / 8;
+          constexpr int kSteps = (C1 - C0 + kWaves - 1) / kWaves;
+          const int Hs = lvH[LV], Ws = lvW[LV], xS = ogx[LV] + lvS[LV], oy = ogy[LV], ox = ogx[LV];
+          int i = C0 + ((wv - C0) & (kWaves - 1));               // this wave's first chunk of the level
+          int subv = sub;
+          asm volatile("" : "+v"(subv));                      // opaque: the level's start is computed HERE
+          const int rel = 8 * (i - C0) + subv;                  // slot of this lane in the level's window
+          int r = (int)(((float)rel + 0.5f) * (1.f / WW)), c = rel - r * WW;
+#pragma unroll
+          for (int t = 0; t < kSteps; ++t, i += kWaves) {
+            const bool have = i < C1;                             // wave-uniform
+            const int y = oy + r;
+            const bool inside = have && (unsigned)y < (unsigned)Hs && (unsigned)(ox + c) < (unsigned)Ws;
+            // pixel index < 2^24 and pixel pitch M * 128 < 2^24 by win_forward_ok: two full-rate 24-bit multiply-adds
+            // (left to the compiler, __mul24 comes back as quarter-rate v_mul_lo_u32)
+            const uint32_t pix = mad_u24((uint32_t)y, (uint32_t)Ws, (uint32_t)(xS + c));
+            const uint32_t in_off = mad_u24(pix, pixB, chunk);
+            const uint32_t off = inside ? in_off : kOobOffset;
+            const int dst = have ? i * 1024 : kZeroOff;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(vsrc, (__attribute__((address_space(3))) void*)(smem + dst), 16,
+                                                     off, hoff, 0, DMA_AUX);
+            c += 64 % WW; r += 64 / WW;
+            if (c >= WW) { c -= WW; r += 1; }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        };
+        stage_level(std::integral_constant<int, 0>{});
+        stage_level(std::integral_constant<int, 1>{});
+        stage_level(std::integral_constant<int, 2>{});
+        stage_level(std::integral_constant<int, 3>{});
+        WIN_STAMP(4);                                            // window DMA issued
+      };
+
       // ---- prepare this lane's four samples ---------------------------------------------------------------------------
       Smp smp[4];
       uint32_t farmask = 0;
       {
-        const uint32_t myWin = smem_base + 128u * (uint32_t)(k == 0 ? kBase[0] : k == 1 ? kBase[1] : k == 2 ? kBase[2] : kBase[3]);
+        const uint32_t myWin = smem_base + (uint32_t)lv2.y;
         const uint32_t zero_first = smem_base + kZeroOff + 128u * (uint32_t)cls_e;        // parity cls_e
         const uint32_t zero_second = smem_base + kZeroOff + 128u * (uint32_t)(cls_e ^ 1);
 #pragma unroll
@@ -394,19 +412,28 @@ __device__ __forceinline__ void win_body(const float* __restrict__ value, const 
           const int src = ((lane & ~3) | fl_) << 2;            // byte address of the preparing lane for ds_bpermute
           // the preparing lane's point `ps`: every lane selects its own candidate, the quad pulls the right one and
           // redoes the (cheap) sample arithmetic -- far samples are a few per cent, their state is not kept around
-          const v2f cxy = ps == 0 ? xy[0] : ps == 1 ? xy[1] : ps == 2 ? xy[2] : xy[3];
-          const float ca = ps == 0 ? sa[0] : ps == 1 ? sa[1] : ps == 2 ? sa[2] : sa[3];
+          // (bit selects, v_bfi_b32: left as ?: chains on register pairs the compiler builds exec-masked branches here)
+          const uint32_t m1 = 0u - (uint32_t)(ps & 1), m2 = 0u - (uint32_t)(ps >> 1);
+          auto sel4 = [&](float a0, float a1, float a2, float a3) __attribute__((always_inline)) {
+            const uint32_t t0 = (__float_as_uint(a1) & m1) | (__float_as_uint(a0) & ~m1);
+            const uint32_t t1 = (__float_as_uint(a3) & m1) | (__float_as_uint(a2) & ~m1);
+            return (int)((t1 & m2) | (t0 & ~m2));
+          };
+          const int cx_ = sel4(xy[0].x, xy[1].x, xy[2].x, xy[3].x), cy_ = sel4(xy[0].y, xy[1].y, xy[2].y, xy[3].y);
+          const int ca_ = sel4(sa[0], sa[1], sa[2], sa[3]);
           // quads without a far sample left run along with zero weights: their stand-in coordinates must be finite
-          const float fxv = has ? __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)__float_as_uint(cxy.x))) : 0.f;
-          const float fyv = has ? __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)__float_as_uint(cxy.y))) : 0.f;
-          const float fav = has ? __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)__float_as_uint(ca))) : 0.f;
-          const int fW = fl_ == 0 ? lvW[0] : fl_ == 1 ? lvW[1] : fl_ == 2 ? lvW[2] : lvW[3];
-          const int fH = fl_ == 0 ? lvH[0] : fl_ == 1 ? lvH[1] : fl_ == 2 ? lvH[2] : lvH[3];
-          const int fS = fl_ == 0 ? lvS[0] : fl_ == 1 ? lvS[1] : fl_ == 2 ? lvS[2] : lvS[3];
+          const uint32_t hm = has ? 0xffffffffu : 0u;
+          const float fxv = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(src, cx_) & hm);
+          const float fyv = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(src, cy_) & hm);
+          const float fav = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(src, ca_) & hm);
+          // the far sample's level constants come from the preparing lane as well (it is lane fl_ of the quad and holds its
+          // own level's): selecting them by fl_ from scalar registers compiles into trees of exec-masked branches
+          const int fW = __builtin_amdgcn_ds_bpermute(src, myW), fH = __builtin_amdgcn_ds_bpermute(src, myH);
+          const int fS = __builtin_amdgcn_ds_bpermute(src, myS);
           const uint32_t rowG = (uint32_t)fW * pixB;
           const float xf = floorf(fxv), yf = floorf(fyv);
           const float lw = fxv - xf, lh = fyv - yf;
-          const int fx0 = has ? (int)xf : 0, fy0 = has ? (int)yf : 0;
+          const int fx0 = (int)xf, fy0 = (int)yf;                // 0 for the stand-ins
           const bool t_ok = has && fy0 >= 0, b_ok = has && fy0 + 1 <= fH - 1, l_ok = fx0 >= 0, r_ok = fx0 + 1 <= fW - 1;
           const float wt = (1.f - lh) * fav, wb = lh * fav;
           f.w1 = wt * (1.f - lw); f.w2 = wt * lw; f.w3 = wb * (1.f - lw); f.w4 = wb * lw;
@@ -421,25 +448,49 @@ __device__ __forceinline__ void win_body(const float* __restrict__ value, const 
           f.d4a = buffer_load_f32x4(vsrc, o4, hoff); f.d4b = buffer_load_f32x4(vsrc, o4 ^ 64u, hoff);
         };
         auto far_consume = [&](const Far& f) __attribute__((always_inline)) {
+          const v2f W1 = {f.w1, f.w1}, W2 = {f.w2, f.w2}, W3 = {f.w3, f.w3}, W4 = {f.w4, f.w4};
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            accA[c] = fmaf(f.w4, f.d4a[c], fmaf(f.w3, f.d3a[c], fmaf(f.w2, f.d2a[c], fmaf(f.w1, f.d1a[c], accA[c]))));
-            accB[c] = fmaf(f.w4, f.d4b[c], fmaf(f.w3, f.d3b[c], fmaf(f.w2, f.d2b[c], fmaf(f.w1, f.d1b[c], accB[c]))));
+          for (int h = 0; h < 2; ++h) {                         // channel pairs: v_pk_fma_f32
+            v2f a = {accA[2 * h], accA[2 * h + 1]}, b = {accB[2 * h], accB[2 * h + 1]};
+            a = __builtin_elementwise_fma(W1, v2f{f.d1a[2 * h], f.d1a[2 * h + 1]}, a);
+            b = __builtin_elementwise_fma(W1, v2f{f.d1b[2 * h], f.d1b[2 * h + 1]}, b);
+            a = __builtin_elementwise_fma(W2, v2f{f.d2a[2 * h], f.d2a[2 * h + 1]}, a);
+            b = __builtin_elementwise_fma(W2, v2f{f.d2b[2 * h], f.d2b[2 * h + 1]}, b);
+            a = __builtin_elementwise_fma(W3, v2f{f.d3a[2 * h], f.d3a[2 * h + 1]}, a);
+            b = __builtin_elementwise_fma(W3, v2f{f.d3b[2 * h], f.d3b[2 * h + 1]}, b);
+            a = __builtin_elementwise_fma(W4, v2f{f.d4a[2 * h], f.d4a[2 * h + 1]}, a);
+            b = __builtin_elementwise_fma(W4, v2f{f.d4b[2 * h], f.d4b[2 * h + 1]}, b);
+            accA[2 * h] = a.x; accA[2 * h + 1] = a.y; accB[2 * h] = b.x; accB[2 * h + 1] = b.y;
           }
           asm volatile("" : "+v"(accA), "+v"(accB));
         };
         Far f0;
+#ifdef MSDA_WIN_NOFAR   // timing experiment only: far samples are dropped (1: everywhere, 2: in round 0, 3: in the later rounds)
+        if (MSDA_WIN_NOFAR == 1 || (MSDA_WIN_NOFAR == 2 && rnd == 0) || (MSDA_WIN_NOFAR == 3 && rnd != 0)) fm = 0;
+#endif
+        // round 0: the loads of the FIRST far step are issued ahead of the window DMA and consumed behind it (they do not
+        // queue behind the CU's whole staging burst, and the wait for them is an exact vmcnt: everything younger is the
+        // fixed number of DMA instructions); the barrier follows, further far steps run after it
+        if (rnd == 0) {
+          far_issue(f0);                                       // unconditional: quads without a far sample load nothing
+          __builtin_amdgcn_sched_barrier(0);
+          stage_windows();
+          __builtin_amdgcn_sched_barrier(0);
+          far_consume(f0);
+        } else if (__ballot(fm != 0u)) {
+          far_issue(f0);
+          far_consume(f0);
+        }
+        if (rnd == 0) {
+          WIN_STAMP(6);                                        // first far step done
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the windows has landed
+          __syncthreads();                                   // ... and everybody else's
+          WIN_STAMP(7);                                        // windows complete
+        }
         while (__ballot(fm != 0u)) {
           far_issue(f0);
           far_consume(f0);
         }
-      }
-
-      if (rnd == 0) {
-        WIN_STAMP(6);                                          // far pass done
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of the windows has landed
-        __syncthreads();                                     // ... and everybody else's
-        WIN_STAMP(7);                                          // windows complete
       }
 
       // ---- the next round's locations and weights travel while this round reads the LDS ----------------------------------
@@ -451,8 +502,8 @@ __device__ __forceinline__ void win_body(const float* __restrict__ value, const 
         const int ql = 1 + (ri >= e1 ? 1 : 0) + (ri >= e2 ? 1 : 0);
         const int j = ri - (ql == 1 ? 0 : ql == 2 ? e1 : e2);
         const int4 ge = *reinterpret_cast<const int4*>(&mt.geo[ql][0]);     // xs, ys, nx of that level
-        const int Wq = ql == 1 ? lvW[1] : ql == 2 ? lvW[2] : lvW[3];
-        const int Sq = ql == 1 ? lvS[1] : ql == 2 ? lvS[2] : lvS[3];
+        const int2 qWS = *reinterpret_cast<const int2*>(&mt.lvl[ql][1]);
+        const int Wq = qWS.x, Sq = qWS.y;
         const int yy = (int)(((float)j + 0.5f) / (float)max(ge.z, 1));
         pair = pair_img + (int64_t)(live ? Sq + (ge.y + yy) * Wq + ge.x + (j - yy * ge.z) : 0) * M + m;
         fetch(k);
