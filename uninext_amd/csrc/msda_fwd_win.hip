@@ -412,12 +412,11 @@ __device__ __forceinline__ void win_body(const float* __restrict__ value, const 
           const int src = ((lane & ~3) | fl_) << 2;            // byte address of the preparing lane for ds_bpermute
           // the preparing lane's point `ps`: every lane selects its own candidate, the quad pulls the right one and
           // redoes the (cheap) sample arithmetic -- far samples are a few per cent, their state is not kept around
-          // (bit selects, v_bfi_b32: left as ?: chains on register pairs the compiler builds exec-masked branches here)
-          const uint32_t m1 = 0u - (uint32_t)(ps & 1), m2 = 0u - (uint32_t)(ps >> 1);
+          // (selects on scalars: as ?: chains on register PAIRS the compiler builds exec-masked branches here)
+          const bool c1 = (ps & 1) != 0, c2 = (ps & 2) != 0;
           auto sel4 = [&](float a0, float a1, float a2, float a3) __attribute__((always_inline)) {
-            const uint32_t t0 = (__float_as_uint(a1) & m1) | (__float_as_uint(a0) & ~m1);
-            const uint32_t t1 = (__float_as_uint(a3) & m1) | (__float_as_uint(a2) & ~m1);
-            return (int)((t1 & m2) | (t0 & ~m2));
+            const float t0 = c1 ? a1 : a0, t1 = c1 ? a3 : a2;   // scalars: v_cndmask_b32
+            return (int)__float_as_uint(c2 ? t1 : t0);
           };
           const int cx_ = sel4(xy[0].x, xy[1].x, xy[2].x, xy[3].x), cy_ = sel4(xy[0].y, xy[1].y, xy[2].y, xy[3].y);
           const int ca_ = sel4(sa[0], sa[1], sa[2], sa[3]);
@@ -430,14 +429,16 @@ __device__ __forceinline__ void win_body(const float* __restrict__ value, const 
           // own level's): selecting them by fl_ from scalar registers compiles into trees of exec-masked branches
           const int fW = __builtin_amdgcn_ds_bpermute(src, myW), fH = __builtin_amdgcn_ds_bpermute(src, myH);
           const int fS = __builtin_amdgcn_ds_bpermute(src, myS);
-          const uint32_t rowG = (uint32_t)fW * pixB;
+          const uint32_t rowG = mad_u24((uint32_t)fW, pixB, 0u);
           const float xf = floorf(fxv), yf = floorf(fyv);
           const float lw = fxv - xf, lh = fyv - yf;
           const int fx0 = (int)xf, fy0 = (int)yf;                // 0 for the stand-ins
           const bool t_ok = has && fy0 >= 0, b_ok = has && fy0 + 1 <= fH - 1, l_ok = fx0 >= 0, r_ok = fx0 + 1 <= fW - 1;
           const float wt = (1.f - lh) * fav, wb = lh * fav;
           f.w1 = wt * (1.f - lw); f.w2 = wt * lw; f.w3 = wb * (1.f - lw); f.w4 = wb * lw;
-          const uint32_t off = (uint32_t)(fS + fy0 * fW + fx0) * pixB + c0;
+          // 24-bit multiply-adds (pixel index < 2^24, pitch < 2^24; a negative fy0 / fx0 only occurs on corners that are
+          // switched off below)
+          const uint32_t off = mad_u24(mad_u24((uint32_t)fy0, (uint32_t)fW, (uint32_t)(fS + fx0)), pixB, c0);
           const uint32_t o1 = (t_ok && l_ok) ? off : kOobOffset;
           const uint32_t o2 = (t_ok && r_ok) ? off + pixB : kOobOffset;
           const uint32_t o3 = (b_ok && l_ok) ? off + rowG : kOobOffset;
