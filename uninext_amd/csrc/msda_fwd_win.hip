@@ -191,23 +191,28 @@ __device__ __forceinline__ void win_body(const float* __restrict__ value, const 
 #endif
     WIN_STAMP(0);
     if (it > 0) __syncthreads();                            // (odd pyramids / persistent grids) everybody left the previous item
-    const int b = (int)(((float)item + 0.5f) / (float)ntiles);
+    // quotients by v_rcp_f32 (the IEEE division sequence is ~10 VALU instructions each, on the critical path of a work
+    // item): x + 0.5 is at least 0.5 / divisor away from an integer, far beyond the 1 ulp of the reciprocal
+    const int b = (int)(((float)item + 0.5f) * __builtin_amdgcn_rcpf((float)ntiles));
     const int64_t pair_img = (int64_t)b * d.Lq * M;         // first (query, head) pair of this item's image
+    const float* const loc_img = loc + pair_img * 32;       // uniform bases: per-lane offsets stay 32-bit (S * M * 128 < 2^31)
+    const float* const attn_img = attn + pair_img * 16;
+    float* const out_img = out + pair_img * 32;
     const __amdgpu_buffer_rsrc_t vsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(value) + (int64_t)b * d.S * M * 32, 0, (int)((uint32_t)d.S * pixB), 0x00020000);
     int (*const sums)[4] = mt.sum[it & 1];
     int nrest;                                              // queries of levels 1..3 of this item, and where they start
     int e1, e2;
     f32x4 lcA, lcB, at;                                     // lane k: the four points of level k -- 32 B + 16 B
-    int64_t pair;
+    uint32_t pair;                                          // (query, head) pair within the image
     bool live;
     auto fetch = [&](int kq) __attribute__((always_inline)) {
       lcA = lcB = at = f32x4{0.f, 0.f, 0.f, 0.f};
       if (live) {
-        const f32x4* lp = reinterpret_cast<const f32x4*>(loc + pair * 32 + 8 * kq);
+        const f32x4* lp = reinterpret_cast<const f32x4*>(loc_img + (pair * 32u + 8u * (uint32_t)kq));
         lcA = __builtin_nontemporal_load(lp);
         lcB = __builtin_nontemporal_load(lp + 1);
-        at = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(attn + pair * 16 + 4 * kq));
+        at = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(attn_img + (pair * 16u + 4u * (uint32_t)kq)));
       }
     };
     {
@@ -218,9 +223,9 @@ __device__ __forceinline__ void win_body(const float* __restrict__ value, const 
       const int kq = lane & 3;
       const int2 gHW = *reinterpret_cast<const int2*>(&mt.lvl[kq][0]);
       const int gW = gHW.y, gH = gHW.x;
-      const float fxs = (float)(kTW * gW) / (float)lvW[0], fys = (float)(kTH * gH) / (float)lvH[0];
+      const float fxs = (float)(kTW * gW) * __builtin_amdgcn_rcpf((float)lvW[0]), fys = (float)(kTH * gH) * __builtin_amdgcn_rcpf((float)lvH[0]);
       const int tile_ = item - b * ntiles;
-      const int ty = (int)(((float)tile_ + 0.5f) / (float)TX), tx = tile_ - ty * TX;
+      const int ty = (int)(((float)tile_ + 0.5f) * __builtin_amdgcn_rcpf((float)TX)), tx = tile_ - ty * TX;
       const int xs = min(max((int)ceilf((float)tx * fxs - 0.5f), 0), gW);
       const int xe = tx == TX - 1 ? gW : min(max((int)ceilf((float)(tx + 1) * fxs - 0.5f), xs), gW);
       const int ys = min(max((int)ceilf((float)ty * fys - 0.5f), 0), gH);
@@ -234,7 +239,7 @@ __device__ __forceinline__ void win_body(const float* __restrict__ value, const 
       // round 0 = the level-0 queries of the tile, wave = tile row, quad = tile column (no division)
       live = pq < (int)qb<0>((uint32_t)nx) && wv < (int)qb<0>((uint32_t)(ye - ys));
       const int q = lvS[0] + ((int)qb<0>((uint32_t)ys) + wv) * lvW[0] + (int)qb<0>((uint32_t)xs) + pq;
-      pair = pair_img + (int64_t)(live ? q : 0) * M + m;
+      pair = mad_u24((uint32_t)(live ? q : 0), (uint32_t)M, (uint32_t)m);
       fetch(kq);
     }
     WIN_STAMP(1);
@@ -495,7 +500,7 @@ __device__ __forceinline__ void win_body(const float* __restrict__ value, const 
       }
 
       // ---- the next round's locations and weights travel while this round reads the LDS ----------------------------------
-      const int64_t cur_pair = pair;
+      const uint32_t cur_pair = pair;
       const bool cur_live = live;
       if (rnd + 1 < nrounds) {                                 // ri-th query of levels 1..3
         const int ri = rnd * kQuads + wv * 16 + pq;
@@ -505,8 +510,9 @@ __device__ __forceinline__ void win_body(const float* __restrict__ value, const 
         const int4 ge = *reinterpret_cast<const int4*>(&mt.geo[ql][0]);     // xs, ys, nx of that level
         const int2 qWS = *reinterpret_cast<const int2*>(&mt.lvl[ql][1]);
         const int Wq = qWS.x, Sq = qWS.y;
-        const int yy = (int)(((float)j + 0.5f) / (float)max(ge.z, 1));
-        pair = pair_img + (int64_t)(live ? Sq + (ge.y + yy) * Wq + ge.x + (j - yy * ge.z) : 0) * M + m;
+        const int yy = (int)(((float)j + 0.5f) * __builtin_amdgcn_rcpf((float)max(ge.z, 1)));
+        const uint32_t qn = mad_u24((uint32_t)(ge.y + yy), (uint32_t)Wq, (uint32_t)(Sq + ge.x + j)) - mad_u24((uint32_t)yy, (uint32_t)ge.z, 0u);
+        pair = mad_u24(live ? qn : 0u, (uint32_t)M, (uint32_t)m);
         fetch(k);
       }
 
@@ -565,7 +571,7 @@ __device__ __forceinline__ void win_body(const float* __restrict__ value, const 
 
       if (rnd == 0) WIN_STAMP(8);                              // LDS pass of the first round done
       if (cur_live) {   // a quad writes 2 x 64 contiguous bytes
-        float* op = out + cur_pair * 32 + 4 * k;
+        float* op = out_img + (cur_pair * 32u + 4u * (uint32_t)k);
         __builtin_nontemporal_store(f32x4{aA0.x, aA0.y, aA1.x, aA1.y}, reinterpret_cast<f32x4*>(op + 16 * cls_a));
         __builtin_nontemporal_store(f32x4{aB0.x, aB0.y, aB1.x, aB1.y}, reinterpret_cast<f32x4*>(op + 16 * (cls_a ^ 1)));
       }
