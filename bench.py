@@ -28,7 +28,7 @@ Extra objects on the JSON line (all measured in this run, after the timed region
                 (ops/test.py:34, no locality) and `wide` (model-like with sigma = 6 px offsets).
   forward_kernels  both encoder-forward kernels pinned (msda_fwd_win: LDS windows; msda_fwd_lg3: gather), launch time
                 on the three flavours, and the far fraction the window kernel reports for each.  The timed region
-                runs variant 0, which follows that report (include/msda_hip.h: window kernel while <= 0.25).
+                runs variant 0, which follows that report (include/msda_hip.h: window kernel while <= 0.20).
   backward      BASELINE configs[4] (training step): the encoder-call and the decoder-call backward launches
                 (grad_value pre-zeroed outside the events): kernel, launch_us, algorithmic bytes
                 (N*(2048*S + 4096*Lq)), achieved GB/s, fraction of 8 TB/s, traffic (as above, or null).
@@ -201,7 +201,7 @@ def measure_flavours(rank, reps=12):
 def measure_forward_kernels(enc, reps=12):
     """Both encoder-forward kernels pinned, on the headline inputs and on the two other flavours, and the sample locality
     the window kernel reports for them.  Variant 0 (`auto`, what the timed region runs) follows that report: window
-    kernel while the far fraction is <= 0.25, gather kernel otherwise (include/msda_hip.h)."""
+    kernel while the far fraction is <= 0.20, gather kernel otherwise (include/msda_hip.h)."""
     out = {}
     S = enc[0]["value"].shape[1]
     alg = workloads.algorithmic_bytes_forward(BATCH, S, S)

@@ -184,7 +184,7 @@ const char* msda_hip_last_kernel(int which);
  * of a query stay within a few pixels of it and slower when they do not, and only the sampling locations tell.  Every
  * launch of the window kernel counts the samples that missed their tile's windows and its last workgroup stores the
  * count in host-mapped memory; variant 0 (automatic) follows the latest report -- window kernel while the far
- * fraction is <= 0.25 -- and, while it runs the gather kernel, sends every 64th call through the window kernel to
+ * fraction is <= 0.20 -- and, while it runs the gather kernel, sends every 64th call through the window kernel to
  * refresh the report.  The choice never changes a result beyond fp32 summation order.  MSDA_HIP_FWD_ADAPTIVE=0 in
  * the environment pins variant 0 to the gather kernel.
  *

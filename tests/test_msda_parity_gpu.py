@@ -97,7 +97,7 @@ def test_window_forward_on_odd_pyramids(levels, flavour, dev, api):
 
 def test_automatic_forward_choice_follows_the_reported_locality(dev, api):
     """include/msda_hip.h: a window-kernel launch reports the fraction of samples that missed its windows; variant 0
-    takes the window kernel while the latest report is <= 0.25 and the gather kernel otherwise, re-probing every
+    takes the window kernel while the latest report is <= 0.20 and the gather kernel otherwise, re-probing every
     64th call.  The choice never changes a result beyond summation order."""
     from uninext_amd import workloads
     MSDA, lib = api

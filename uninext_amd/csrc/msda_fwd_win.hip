@@ -44,9 +44,9 @@ namespace {
 
 constexpr int kT = 512, kWaves = kT / 64, kQuads = kT / 4;
 // auto dispatch (win_forward_auto): the window kernel is used while the last reported far fraction is at most this
-// (kbench flavours: model 0.1x -> window kernel ahead, wide / uniform -> msda_fwd_lg3 ahead; profiles/), and the
-// statistic is refreshed every kReprobe-th call otherwise
-constexpr double kFarFractionMax = 0.25;
+// (bench flavours: far 0.02 -> 78 us against 107 for msda_fwd_lg3, 0.41 -> 147 against 101-123, 0.93 -> 184 against
+// 106-121: the lines cross near 0.2), and the statistic is refreshed every kReprobe-th call otherwise
+constexpr double kFarFractionMax = 0.20;
 constexpr unsigned kReprobe = 64;
 constexpr int kTH = 8, kTW = 16;
 constexpr int kWH[4] = {14, 10, 8, 7};
