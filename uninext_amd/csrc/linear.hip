@@ -14,6 +14,7 @@
 #include "msda_common.hpp"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace linear {
 
@@ -250,41 +251,72 @@ linear_packed(const float* __restrict__ x, const float* __restrict__ x2, const u
     layernorm_epilogue<WJ>(acc, bias, ln, reinterpret_cast<float*>(&As[0][0][0][0][0]), m0, M, N, wn, tid, out);
     return;
   }
-  // epilogue: accumulator register v of lane l is (row 8 (v / 4) + 4 (l / 32) + v % 4, column l % 32)
+  // epilogue: accumulator register v of lane l is (row 8 (v / 4) + 4 (l / 32) + v % 4, column l % 32).
+  // All per-element arithmetic is 32-bit and relative to the workgroup's tile: the tile's first row goes into a
+  // uniform 64-bit base once (m * N + n per element in 64 bits was two quarter-rate multiplies, a 64-bit compare and --
+  // on the head-major path -- a 64-bit DIVISION per stored value: more issue time than the tile's MFMAs).
+  const int rows_here = (int)((M - m0) < (long long)BM ? (M - m0) : (long long)BM);   // valid rows of this tile
+  // head-major output [image, head = n / 32, row in image, n % 32]: a tile of BM <= hm_rows rows touches at most two images
+  long long img0 = 0;
+  int first_sr = 0;                                   // row inside image img0 of the tile's first row
+  if (hm_rows != 0) {
+    img0 = m0 / hm_rows;                              // uniform: once per workgroup
+    first_sr = (int)(m0 - img0 * hm_rows);
+  }
+  float* const out_tile = hm_rows == 0 ? out + m0 * N : out + img0 * (long long)(N / 32) * hm_rows * 32;
 #pragma unroll
   for (int i = 0; i < TI; ++i) {
     uint32_t zero_rows = 0;                            // bit v: row of register v is masked
     if (row_mask) {
 #pragma unroll
       for (int v4 = 0; v4 < 4; ++v4) {                 // rows 8 v4 + 4 half .. + 3 are consecutive: one 4-byte load
-        const long long m = m0 + wm + i * 32 + 8 * v4 + 4 * half;
+        const int rt = wm + i * 32 + 8 * v4 + 4 * half;   // row inside the tile (a multiple of 4; m0 is a multiple of BM)
         uint32_t four = 0;
-        if (m + 3 < M && ((m & 3) == 0)) four = *reinterpret_cast<const uint32_t*>(row_mask + m);
+        if (rt + 3 < rows_here) four = *reinterpret_cast<const uint32_t*>(row_mask + m0 + rt);
         else
-          for (int e = 0; e < 4; ++e) if (m + e < M && row_mask[m + e]) four |= 0xffu << (8 * e);
+          for (int e = 0; e < 4; ++e) if (rt + e < rows_here && row_mask[m0 + rt + e]) four |= 0xffu << (8 * e);
 #pragma unroll
         for (int e = 0; e < 4; ++e) if ((four >> (8 * e)) & 0xffu) zero_rows |= 1u << (4 * v4 + e);
       }
     }
+    // offset of this lane's first row (4 * half) of row tile i; the other rows are compile-time multiples of N away
+    // (scalar multiplies: N is uniform)
+    const uint32_t lane_row = (uint32_t)(wm + i * 32 + 4 * half);
+    auto store_tile = [&](auto full_tag) __attribute__((always_inline)) {
+      constexpr bool FULL = decltype(full_tag)::value;   // the whole tile is inside the matrix: no per-element checks
 #pragma unroll
-    for (int jn = 0; jn < WJ; ++jn) {
-      const int n = n0 + wn + jn * 32 + r32;
-      const float bv = (bias && n < N) ? bias[n] : 0.f;
+      for (int jn = 0; jn < WJ; ++jn) {
+        const int n = n0 + wn + jn * 32 + r32;
+        const bool n_ok = FULL || n < N;
+        const float bv = (bias && n_ok) ? bias[n] : 0.f;
+        // element offset of (row, column n) inside the tile's output: row-major, or head-major with the image switch
+        const uint32_t col_off = hm_rows == 0 ? (uint32_t)n : (uint32_t)(n >> 5) * (uint32_t)hm_rows * 32u + (uint32_t)(n & 31);
+        const uint32_t base_off = hm_rows == 0 ? lane_row * (uint32_t)N + col_off : col_off;
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const long long m = m0 + wm + i * 32 + 8 * (v / 4) + 4 * half + (v % 4);
-        if (m < M && n < N) {
-          float r = ((zero_rows >> v) & 1u) ? 0.f : acc[i][jn][v] + bv;
-          if (act == 1) r = fmaxf(r, 0.f);
-          if (hm_rows == 0) {
-            out[m * N + n] = r;
-          } else {   // head-major [image, head = n / 32, row in image, n % 32]: a lane row still writes 128 contiguous bytes
-            const long long img = m / hm_rows, sr = m - img * hm_rows;
-            out[((img * (N / 32) + (n >> 5)) * hm_rows + sr) * 32 + (n & 31)] = r;
+        for (int v = 0; v < 16; ++v) {
+          constexpr int kDummy = 0;
+          (void)kDummy;
+          const int dr = 8 * (v / 4) + (v % 4);            // compile-time row distance from lane_row
+          const int rt = (int)lane_row + dr;
+          if (FULL || (rt < rows_here && n_ok)) {
+            float r = ((zero_rows >> v) & 1u) ? 0.f : acc[i][jn][v] + bv;
+            if (act == 1) r = fmaxf(r, 0.f);
+            uint32_t off;
+            if (hm_rows == 0) {
+              off = base_off + (uint32_t)dr * (uint32_t)N;
+            } else {
+              int sr = first_sr + rt;                     // row inside image img0, or past its end: the next image
+              uint32_t img_off = 0;
+              if (sr >= hm_rows) { sr -= hm_rows; img_off = (uint32_t)(N / 32) * (uint32_t)hm_rows * 32u; }
+              off = img_off + (uint32_t)sr * 32u + base_off;
+            }
+            out_tile[off] = r;
           }
         }
       }
-    }
+    };
+    if (rows_here == BM && n0 + 64 * TJ <= N) store_tile(std::true_type{});
+    else store_tile(std::false_type{});
   }
 }
 
@@ -558,7 +590,7 @@ static int linear_impl(const float* x, const float* x2, const void* packed, cons
   // a CU can overlap -- 33 KB of LDS each instead of 66 KB
   constexpr int BM = 64;
   const long long mt = (rows + BM - 1) / BM;
-  if (mt >= (1ll << 31) || (long long)(out_features + 63) / 64 > 65535)
+  if (mt >= (1ll << 31) || (long long)(out_features + 63) / 64 > 65535 || out_features >= (1 << 24))
     return dynmask_set_error(LINEAR_ERR_BAD_DIMS, "linear: problem too large");
   if (!x || !packed || !out) return dynmask_set_error(LINEAR_ERR_NULL_POINTER, "linear: null pointer argument");
   const int n_pad = linear::n_padded(out_features);
@@ -605,6 +637,9 @@ int linear_hip_packed_hm_f32(const float* x, const void* packed, const float* bi
                              void* stream) {
   if (rows_per_image <= 0 || out_features % 32 != 0 || (rows >= 0 && rows % rows_per_image != 0))
     return dynmask_set_error(LINEAR_ERR_BAD_DIMS, "linear (head-major): out_features must be a multiple of 32 and rows a multiple of rows_per_image");
+  // the epilogue addresses an image pair with 32-bit element offsets and lets a 64-row tile straddle one image boundary
+  if (rows_per_image < 64 || (long long)rows_per_image * out_features >= (1ll << 30))
+    return dynmask_set_error(LINEAR_ERR_UNSUPPORTED, "linear (head-major): rows_per_image must be >= 64 and rows_per_image * out_features < 2^30");
   return linear_impl(x, nullptr, packed, bias, row_mask, rows, in_features, out_features, rows_per_image, 0, out, stream);
 }
 
