@@ -67,6 +67,11 @@ __device__ __forceinline__ void layernorm_epilogue(const f32x16 (&acc)[2][WJ], c
     v += msda_dpp<0xB1>(v); v += msda_dpp<0x4E>(v); v += msda_dpp<0x141>(v); v += msda_dpp<0x140>(v);
     return v + __shfl_xor(v, 16, 64);
   };
+  const int rows_here = (int)((M - m0) < 64ll ? (M - m0) : 64ll);
+  const bool full = rows_here == 64;
+  const float* const res_tile = ln.residual ? ln.residual + m0 * N : nullptr;
+  float* const out_tile = out + m0 * N;
+  const uint32_t lane_off = (uint32_t)(4 * half) * (uint32_t)N;
   float val[TI][WJ][16];
 #pragma unroll
   for (int i = 0; i < TI; ++i)
@@ -76,9 +81,15 @@ __device__ __forceinline__ void layernorm_epilogue(const f32x16 (&acc)[2][WJ], c
       const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
-        long long m = m0 + i * 32 + 8 * (v / 4) + 4 * half + (v % 4);
-        m = m < M ? m : M - 1;
-        val[i][jn][v] = acc[i][jn][v] + bv + (ln.residual ? ln.residual[m * N + n] : 0.f);
+        // 32-bit offsets inside the workgroup's 64-row tile (its first row sits in the uniform bases): per element in 64
+        // bits this was two quarter-rate multiplies and a 64-bit compare.  Full tiles: lane part + a scalar multiple of N
+        const int dr = i * 32 + 8 * (v / 4) + (v % 4);
+        uint32_t off = lane_off + (uint32_t)n + (uint32_t)dr * (uint32_t)N;
+        if (!full) {
+          const int rt = dr + 4 * half;
+          off = (uint32_t)(rt < rows_here ? rt : rows_here - 1) * (uint32_t)N + (uint32_t)n;
+        }
+        val[i][jn][v] = acc[i][jn][v] + bv + (ln.residual ? res_tile[off] : 0.f);
       }
     }
   float stat[TI][16];
@@ -125,9 +136,10 @@ __device__ __forceinline__ void layernorm_epilogue(const f32x16 (&acc)[2][WJ], c
       const float gmm = ln.gamma ? ln.gamma[n] : 1.f, bt = ln.beta ? ln.beta[n] : 0.f;
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
-        const long long m = m0 + i * 32 + 8 * (v / 4) + 4 * half + (v % 4);
+        const int dr = i * 32 + 8 * (v / 4) + (v % 4);
         const float rstd = rsqrtf(stat[i][v] * inv_n + ln.eps);
-        if (m < M) out[m * N + n] = (val[i][jn][v] - mean[i][v]) * rstd * gmm + bt;
+        if (full || dr + 4 * half < rows_here)
+          out_tile[lane_off + (uint32_t)n + (uint32_t)dr * (uint32_t)N] = (val[i][jn][v] - mean[i][v]) * rstd * gmm + bt;
       }
     }
 }
@@ -291,7 +303,8 @@ linear_packed(const float* __restrict__ x, const float* __restrict__ x2, const u
         const float bv = (bias && n_ok) ? bias[n] : 0.f;
         // element offset of (row, column n) inside the tile's output: row-major, or head-major with the image switch
         const uint32_t col_off = hm_rows == 0 ? (uint32_t)n : (uint32_t)(n >> 5) * (uint32_t)hm_rows * 32u + (uint32_t)(n & 31);
-        const uint32_t base_off = hm_rows == 0 ? lane_row * (uint32_t)N + col_off : col_off;
+        uint32_t base_off = hm_rows == 0 ? lane_row * (uint32_t)N + col_off : col_off;
+        asm volatile("" : "+v"(base_off));   // opaque: `base_off + scalar` per element stays an add (see conv3x3.hip)
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
           constexpr int kDummy = 0;
