@@ -144,18 +144,15 @@ conv3x3_gemm(const float* __restrict__ in, const float* __restrict__ w, const fl
   for (int i = 0; i < TI; ++i) {
     const int m = m0 + wm + i * 32 + r32;
     const int b = m / HW, sp = m - b * HW;
-    float* const out_b = out + (int64_t)b * g.Cout * HW;
 #pragma unroll
     for (int jn = 0; jn < TJ; ++jn)
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
-        const int dn = jn * 32 + 8 * (v / 4) + (v % 4);    // compile-time channel distance from the lane's first row
-        const int n = n0 + wn + 4 * half + dn;
+        const int n = n0 + wn + jn * 32 + 8 * (v / 4) + 4 * half + (v % 4);
         if (m < g.Mtot && n < g.Cout) {
           float r = acc[i][jn][v] + (bias ? bias[n] : 0.f);
           if (RELU) r = fmaxf(r, 0.f);
-          // image base in 64 bits once per row tile, 32-bit offsets below it (cout * H * W < 2^31)
-          out_b[(uint32_t)(n0 + wn + 4 * half) * (uint32_t)HW + (uint32_t)sp + (uint32_t)dn * (uint32_t)HW] = r;
+          out[((int64_t)b * g.Cout + n) * HW + sp] = r;
         }
       }
   }
@@ -285,18 +282,15 @@ conv3x3_gemm_bf16x3(const float* __restrict__ in, const float* __restrict__ w, c
   for (int i = 0; i < TI; ++i) {
     const int m = m0 + wm + i * 32 + r32;
     const int b = m / HW, sp = m - b * HW;
-    float* const out_b = out + (int64_t)b * g.Cout * HW;
 #pragma unroll
     for (int jn = 0; jn < TJ; ++jn)
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
-        const int dn = jn * 32 + 8 * (v / 4) + (v % 4);    // compile-time channel distance from the lane's first row
-        const int n = n0 + wn + 4 * half + dn;
+        const int n = n0 + wn + jn * 32 + 8 * (v / 4) + 4 * half + (v % 4);
         if (m < g.Mtot && n < g.Cout) {
           float r = acc[i][jn][v] + (bias ? bias[n] : 0.f);
           if (RELU) r = fmaxf(r, 0.f);
-          // image base in 64 bits once per row tile, 32-bit offsets below it (cout * H * W < 2^31)
-          out_b[(uint32_t)(n0 + wn + 4 * half) * (uint32_t)HW + (uint32_t)sp + (uint32_t)dn * (uint32_t)HW] = r;
+          out[((int64_t)b * g.Cout + n) * HW + sp] = r;
         }
       }
   }
@@ -338,7 +332,7 @@ conv3x3_packed(const float* __restrict__ in, const uint32_t* __restrict__ packed
   const int HW = g.H * g.W;
 
   // ---- halo staging: items (halo pixel, channel half); this thread owns items tid and tid + 256 ----------------
-  uint32_t h_off[2];
+  const float* h_ptr[2];
   bool h_ok[2], h_has[2];
   int h_px[2], h_half[2];
 #pragma unroll
@@ -350,18 +344,14 @@ conv3x3_packed(const float* __restrict__ in, const uint32_t* __restrict__ packed
     h_half[r] = (item / kHaloPx) & 1;
     const int gy = ty0 - 1 + hp / kHaloW, gx = tx0 - 1 + hp % kHaloW;
     h_ok[r] = h_has[r] && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
-    h_off[r] = (uint32_t)(h_half[r] * 8) * (uint32_t)HW + (uint32_t)(h_ok[r] ? gy * g.W + gx : 0);
+    h_ptr[r] = in + ((int64_t)b * g.Cin + h_half[r] * 8) * HW + (h_ok[r] ? gy * g.W + gx : 0);
   }
-  // uniform 64-bit base per (image, chunk), 32-bit lane offsets below it (a chunk spans 16 * H * W elements < 2^31):
-  // in 64 bits per element this was a quarter-rate multiply-add per load
-  const float* const in_img = in + (int64_t)b * g.Cin * HW;
   float h_reg[2][8];
   auto load_halo = [&](int chunk) {
-    const float* const cb = in_img + (int64_t)chunk * kChunk * HW;
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) h_reg[r][e] = h_ok[r] ? cb[h_off[r] + (uint32_t)e * (uint32_t)HW] : 0.f;
+      for (int e = 0; e < 8; ++e) h_reg[r][e] = h_ok[r] ? h_ptr[r][(int64_t)(chunk * kChunk + e) * HW] : 0.f;
   };
   auto store_halo = [&](int buf) {
 #pragma unroll
@@ -446,28 +436,19 @@ conv3x3_packed(const float* __restrict__ in, const uint32_t* __restrict__ packed
   }
 
   // ---- epilogue: accumulator register v of lane l is (channel row 8 (v / 4) + 4 (l / 32) + v % 4, pixel l % 32) ------
-  // 32-bit offsets inside the image's output (cout * H * W < 2^31, checked by the host): the image base is uniform, the
-  // lane contributes its pixel and its first channel row, the other rows are scalar multiples of H * W away
-  float* const out_img = out + (int64_t)b * g.Cout * HW;
-  const int n_lane = n0 + wn * 32 * WJ + 4 * half;
-  const bool n_full = n0 + wn * 32 * WJ + 32 * WJ <= g.Cout;     // wave-uniform: no per-channel check needed
 #pragma unroll
   for (int i = 0; i < TI; ++i) {
     const int gy = ty0 + wm * 2 * TI + i * 2 + (r32 >> 4), gx = tx0 + (r32 & 15);
     const bool pix_ok = gy < g.H && gx < g.W;
-    uint32_t lane_off = (uint32_t)n_lane * (uint32_t)HW + (uint32_t)(gy * g.W + gx);
-    asm volatile("" : "+v"(lane_off));   // opaque: keeps `lane_off + scalar` per element (re-associated, it becomes one
-                                           // quarter-rate 64-bit multiply-add per stored value)
 #pragma unroll
     for (int jn = 0; jn < WJ; ++jn)
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
-        const int dn = jn * 32 + 8 * (v / 4) + (v % 4);    // compile-time channel distance from n_lane
-        const int n = n_lane + dn;
-        if (pix_ok && (n_full || n < g.Cout)) {
+        const int n = n0 + wn * 32 * WJ + jn * 32 + 8 * (v / 4) + 4 * half + (v % 4);
+        if (pix_ok && n < g.Cout) {
           float r = acc[i][jn][v] + (bias ? bias[n] : 0.f);
           if (RELU) r = fmaxf(r, 0.f);
-          out_img[lane_off + (uint32_t)dn * (uint32_t)HW] = r;
+          out[((int64_t)b * g.Cout + n) * HW + gy * g.W + gx] = r;
         }
       }
   }
@@ -540,8 +521,7 @@ int conv3x3_hip_f32(const float* in, const float* weight, const float* bias, int
     return dynmask_set_error(CONV3X3_ERR_UNSUPPORTED, "conv3x3: 9 * cin must be a multiple of 16");
   const long long M = (long long)batch * height * width;
   if (M == 0) return 0;
-  if (M >= (1ll << 31) || K >= (1ll << 31) || (long long)(cout + 63) / 64 > 65535 ||
-      (long long)(cout + 127) * height * width >= (1ll << 31))
+  if (M >= (1ll << 31) || K >= (1ll << 31) || (long long)(cout + 63) / 64 > 65535)
     return dynmask_set_error(CONV3X3_ERR_BAD_DIMS, "conv3x3: problem too large");
   if (!in || !weight || !out) return dynmask_set_error(CONV3X3_ERR_NULL_POINTER, "conv3x3: null pointer argument");
   conv3x3::Geom g;
@@ -588,8 +568,7 @@ int conv3x3_hip_packed_f32(const float* in, const void* packed, const float* bia
   if (M == 0) return 0;
   const int tiles_x = (width + conv3x3::kTW - 1) / conv3x3::kTW, tiles_y = (height + conv3x3::kTH - 1) / conv3x3::kTH;
   const long long tiles = (long long)batch * tiles_x * tiles_y;
-  if (M >= (1ll << 31) || tiles >= (1ll << 31) || (long long)cin * height * width >= (1ll << 31) ||
-      (long long)(cout + 127) * height * width >= (1ll << 31))
+  if (M >= (1ll << 31) || tiles >= (1ll << 31) || (long long)cin * height * width >= (1ll << 31))
     return dynmask_set_error(CONV3X3_ERR_BAD_DIMS, "conv3x3: problem too large");
   if (!in || !packed || !out) return dynmask_set_error(CONV3X3_ERR_NULL_POINTER, "conv3x3: null pointer argument");
   conv3x3::Geom g;
