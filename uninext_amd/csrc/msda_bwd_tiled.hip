@@ -71,14 +71,22 @@ __device__ __forceinline__ float bdpp(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 __device__ __forceinline__ float group8_sum(float v) {  // over the 8 lanes of a pair; every lane gets the total
-  v += bdpp<0xB1>(v);   // quad_perm [1,0,3,2]
-  v += bdpp<0x4E>(v);   // quad_perm [2,3,0,1]
-  v += bdpp<0x141>(v);  // row_half_mirror
+  // v_add_f32 with the DPP modifier on its first source: one instruction per butterfly step (the compiler keeps
+  // v_mov_b32_dpp + v_add_f32 apart for float adds -- 9 extra VALU instructions per sample step)
+  // (s_nop 1: a DPP read of a VGPR needs two wait states after the VALU write of it; the compiler does not see into
+  // the asm and would not insert them)
+  asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(v) : "v"(v));
+  asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(v) : "v"(v));
+  asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(v) : "v"(v));
   return v;
 }
 
 typedef int __attribute__((address_space(3)))* lds_int_ptr;
 __device__ __forceinline__ void lds_add(uint32_t lds_byte_addr, int v) {   // ds_add_u32, no return value
+#ifdef MSDA_BWD_NOADD   // timing experiment only (wrong results): the value-gradient accumulation is dropped
+  asm volatile("" :: "v"(lds_byte_addr), "v"(v));
+  return;
+#endif
   __hip_atomic_fetch_add(reinterpret_cast<lds_int_ptr>((uintptr_t)lds_byte_addr), v, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -455,6 +463,9 @@ msda_bwd_tiled(const float* __restrict__ grad_out, const float* __restrict__ val
           // -- far samples of this pass: the value gradient w_k * a * g_c does not depend on the sampled values,
           //    so a half-wave (32 lanes = 32 channels) redoes it from the record and the upstream gradient and
           //    issues ONE full-line atomic per live corner.
+#ifdef MSDA_BWD_NOFAR   // timing experiment only (wrong results): far samples are dropped
+          far_any = 0;
+#endif
           if (far_any) {
             const int hl = lane & 31;
 #pragma unroll 1
