@@ -36,9 +36,22 @@ msda_bwd_generic(const T* __restrict__ grad_out, const T* __restrict__ value,
   const int64_t pix_stride = (int64_t)d.M * d.D;
   const int LP = d.L * d.P;
   auto group_sum = [](T v) {
+    if constexpr (sizeof(T) == 4) {
+      // float: four DPP butterfly steps inside a row of 16 and one cross-row exchange per 32 lanes (the shuffle loop is a
+      // chain of five or six dependent ds_bpermute round trips per value, three values per sample)
+      float f = (float)v;
+      f += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+      f += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+      f += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0x141, 0xF, 0xF, true));   // row_half_mirror
+      f += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0x140, 0xF, 0xF, true));   // row_mirror
+      f += __shfl_xor(f, 16, 64);
+      if constexpr (kLanes == 64) f += __shfl_xor(f, 32, 64);
+      return (T)f;
+    } else {
 #pragma unroll
-    for (int o = kLanes / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+      for (int o = kLanes / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      return v;
+    }
   };
   for (int64_t pair0 = (int64_t)blockIdx.x * kPairsPerBlock + threadIdx.x / kLanes; ; pair0 += (int64_t)gridDim.x * kPairsPerBlock) {
     // the two halves of a wave run in lock step: a half past the end idles through the loop with `live` off
