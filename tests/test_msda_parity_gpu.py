@@ -15,6 +15,8 @@ north_star: "outputs match the reference's ms_deform_attn_core_pytorch CPU fallb
                                           reference itself; the bound says "no worse than float32 allows".
 The checker is the C oracle (oracle/msda_oracle.c, pinned to reference-minted fixtures by tests/test_oracle_golden.py),
 run over all N * Lq * M pairs -- a few seconds per call at the R50 shapes."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -233,3 +235,35 @@ def test_full_size_decoder_backward_every_query(dev, api):
     d_gl = np.abs(gl.cpu().numpy().astype(np.float64) - ogl)
     for l, (h, w) in enumerate(workloads.R50_LEVELS_INFER):
         assert float(d_gl[:, :, :, l].max()) < 1e-4 * max(h, w)
+
+
+def test_first_encoder_call_of_a_process_inside_a_graph_capture(dev):
+    """The automatic choice sets its locality report up on first use (pinned host memory, a copy to a device symbol):
+    not inside a stream capture.  A process whose FIRST encoder-shaped call is captured must still capture, replay and
+    agree with an eager call (it runs the gather kernel there); later eager calls take the window kernel as usual."""
+    import subprocess
+    import sys
+    script = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from uninext_amd import _lib, workloads
+import MultiScaleDeformableAttention as MSDA
+x = workloads.make_inputs("encoder", "model", batch=1, levels=((40, 56), (20, 28), (10, 14), (5, 7)), seed=5, device="cuda")
+torch.cuda.synchronize()
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g):
+    cap = MSDA.ms_deform_attn_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], 64)
+captured_kernel = _lib.last_kernel("forward")
+cap.zero_()
+g.replay()
+torch.cuda.synchronize()
+eager = MSDA.ms_deform_attn_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], 64)
+eager_kernel = _lib.last_kernel("forward")
+torch.cuda.synchronize()
+assert float((cap - eager).abs().max()) < 2e-5, float((cap - eager).abs().max())
+print("KERNELS", captured_kernel, eager_kernel, _lib.forward_locality()[0])
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("KERNELS")][0].split()
+    assert line[1] == "msda_fwd_lg3" and line[2] == "msda_fwd_win" and int(line[3]) == 1, line

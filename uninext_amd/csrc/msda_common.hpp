@@ -116,7 +116,7 @@ int launch_backward_tiled(const float* grad_out, const float* value, const int64
 
 // msda_fwd_win.hip: encoder forward with LDS windows on all four levels (fp32, D = 32, L = P = 4, Lq == S).
 bool win_forward_ok(const Dims& d);
-bool win_forward_auto(const Dims& d);            // auto dispatch: take the window kernel for this call?
+bool win_forward_auto(const Dims& d, hipStream_t stream);   // auto dispatch: take the window kernel for this call?
 int forward_locality(double* far_fraction);      // reports so far (0: none yet) and the last one's far fraction
 int launch_forward_win(const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc, const float* attn,
                        const Dims& d, float* out, hipStream_t stream);

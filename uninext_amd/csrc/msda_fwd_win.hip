@@ -645,10 +645,14 @@ LocalityState g_loc[kMaxDevices];
 std::atomic<int> g_loc_ready[kMaxDevices];
 std::mutex g_loc_mutex;
 
-LocalityState* locality_state() {
+LocalityState* locality_state(hipStream_t stream) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
   if (g_loc_ready[dev].load(std::memory_order_acquire) == 1) return &g_loc[dev];
+  // first use on this device: allocates and copies -- not inside a stream capture (the caller then runs without the
+  // statistic: the plain copy of the kernel, or msda_fwd_lg3 under variant 0)
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (stream && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return nullptr;
   std::lock_guard<std::mutex> lock(g_loc_mutex);
   if (g_loc_ready[dev].load(std::memory_order_relaxed) == 1) return &g_loc[dev];
   if (g_loc_ready[dev].load(std::memory_order_relaxed) == -1) return nullptr;
@@ -673,7 +677,7 @@ LocalityState* locality_state() {
 }  // namespace
 
 int forward_locality(double* far_fraction) {
-  LocalityState* st = locality_state();
+  LocalityState* st = locality_state(nullptr);
   if (!st) return 0;
   const unsigned long long w = *st->report;
   const unsigned long long f = w & ((1ull << kStatPairShift) - 1ull);
@@ -692,10 +696,10 @@ int forward_locality(double* far_fraction) {
 // tile stay near it and loses (up to 1.7x) when they do not, and only the locations know which.  Every launch of the
 // window kernel reports the far fraction of its own inputs; the next calls follow the latest report, and while they
 // run the other kernel every kReprobe-th call goes through the window kernel again to refresh it.
-bool win_forward_auto(const Dims& d) {
+bool win_forward_auto(const Dims& d, hipStream_t stream) {
   static const int mode = [] { const char* e = std::getenv("MSDA_HIP_FWD_ADAPTIVE"); return e ? std::atoi(e) : 1; }();
   if (mode == 0 || !win_forward_ok(d)) return false;
-  LocalityState* st = locality_state();
+  LocalityState* st = locality_state(stream);
   if (!st) return false;
   double far = 0.0;
   const int seq = forward_locality(&far);
@@ -711,12 +715,12 @@ int launch_forward_win(const float* value, const int64_t* shapes, const int64_t*
                        const Dims& d, float* out, hipStream_t stream) {
   static const bool nt = std::getenv("MSDA_WIN_NT") && std::getenv("MSDA_WIN_NT")[0] == '1';   // A/B switch
   static std::atomic<uint64_t> lds_opted_in[3] = {{0}, {0}, {0}};
-  static const bool stat = !(std::getenv("MSDA_WIN_STAT") && std::getenv("MSDA_WIN_STAT")[0] == '0');   // A/B switch
-  const auto kern = nt ? msda_fwd_win<2, true> : (stat ? msda_fwd_win<0, true> : msda_fwd_win<0, false>);
+  static const bool stat_env = !(std::getenv("MSDA_WIN_STAT") && std::getenv("MSDA_WIN_STAT")[0] == '0');   // A/B switch
+  // the counting copy of the kernel writes its report through g_locality.report: only once that is set up
+  const bool stat = stat_env && locality_state(stream) != nullptr;
+  const auto kern = stat ? (nt ? msda_fwd_win<2, true> : msda_fwd_win<0, true>) : msda_fwd_win<0, false>;
   const void* fn = reinterpret_cast<const void*>(kern);
-  if (int rc = ensure_dynamic_lds(fn, kLdsBytes, lds_opted_in[nt ? 1 : (stat ? 0 : 2)])) return rc;
-  LocalityState* st = locality_state();
-  if (!st) return (int)hipErrorOutOfMemory;
+  if (int rc = ensure_dynamic_lds(fn, kLdsBytes, lds_opted_in[stat ? (nt ? 1 : 0) : 2])) return rc;
   // Workgroups per head.  Default: one work item per workgroup -- the host only knows S, so ceil(S / 128) per image,
   // at least the tile count of any pyramid whose level 0 holds <= ~3/4 of the pixels; the surplus exits at once and the
   // dispatcher staggers the rest, which keeps the memory / LDS / VALU phases of neighbouring workgroups out of step.
