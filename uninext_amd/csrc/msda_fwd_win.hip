@@ -26,8 +26,17 @@
 //                pixel parity) orders over the two x-adjacent corners of a bilinear row, so that in every
 //                instruction the group covers all 64 banks exactly once, for any sample position.
 //   far        = an in-range sample with a corner outside its window takes raw buffer loads (invalid corners at an
-//                out-of-range offset), in a pass that runs while the window DMA is still in flight.  Correctness
-//                never depends on where the windows are; only speed does (uniform-random locations are all far).
+//                out-of-range offset), one far sample per quad and step; in round 0 the loads of the first step are
+//                issued ahead of the window DMA and consumed behind it.  Correctness never depends on where the
+//                windows are; only speed does (uniform-random locations are all far).
+//   statistic  = one workgroup in 16 runs a copy of the body that counts its far samples; the last of them stores the
+//                launch's totals as one 8-byte word into host-mapped memory, which the host's automatic kernel choice
+//                reads without a sync (win_forward_auto below, include/msda_hip.h).
+//
+// Instruction-stream notes (profiles/r02_window_forward_experiments.txt): per-level constants come from an LDS table and
+// the far sample's level constants by ds_bpermute -- `k == 0 ? a : k == 1 ? b : ...` on scalar registers compiles into
+// trees of exec-masked branches; 24-bit multiply-adds are inline asm (v_mad_u32_u24) -- __mul24 comes back as quarter-rate
+// v_mul_lo_u32; quotients use v_rcp_f32; (query, head) pair indices are 32-bit below uniform per-image base pointers.
 //
 // All geometry comes from the int64 shape tensors on the device; the host only knows S, so the grid has
 // ceil(S / 128) workgroups per (image, head) -- at least the number of tiles of any pyramid whose level 0 holds
@@ -401,9 +410,7 @@ __device__ __forceinline__ void win_body(const float* __restrict__ value, const 
       f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};   // channels at c0 and at c0 ^ 64
       if (rnd == 0) WIN_STAMP(5);                              // samples prepared
 
-      // ---- far samples: raw buffer loads, one far sample per quad and step (behind the window DMA in round 0: vmcnt is
-      // in order, so this pass also sits out most of the DMA's latency; issuing its loads ahead of an unrolled,
-      // fixed-count DMA was tried and cost > 100 spilled registers) ---------------------------------------------------------
+      // ---- far samples: raw buffer loads, one far sample per quad and step ------------------------------------------------
       {
         uint32_t fm = farmask << (4 * k);                      // the pair's 16 samples: bit 4 * level + point
         fm |= (uint32_t)dppi<0xB1>((int)fm);                   // quad_perm [1,0,3,2]
