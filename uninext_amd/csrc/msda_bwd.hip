@@ -61,6 +61,68 @@ msda_bwd_generic(const T* __restrict__ grad_out, const T* __restrict__ value,
     const int m = (int)(pair % d.M);
     const int64_t b = pair / ((int64_t)d.M * d.Lq);
     const T* g_ptr = grad_out + pair * d.D;
+    if constexpr (HALF == 1 && sizeof(T) == 4) {
+      // D <= 32, float: one channel per lane.  The points of a level are taken four at a time -- all four are prepared
+      // and their 16 corner loads issued before the first one is consumed, so a pair pays one memory round trip per
+      // four samples instead of one per sample (this path is what the decoder-call backward runs; it is bound by the
+      // L2 atomic rate, the round trips were the part above that bound)
+      const bool ch = lane < d.D;
+      const T g = ch ? g_ptr[lane] : (T)0;
+      for (int l = 0; l < d.L; ++l) {
+        const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+        const int64_t lvl_off = (b * d.S + lsi[l]) * pix_stride + (int64_t)m * d.D + lane;
+        for (int p0 = 0; p0 < d.P; p0 += 4) {
+          Sample<T> s[4];
+          T a[4], v[4][4];
+          int64_t o1[4];
+          bool in[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const bool have = p0 + k < d.P;
+            const int64_t si = pair * LP + l * d.P + (have ? p0 + k : 0);
+            a[k] = attn[si];
+            s[k] = make_sample<T>(loc[si * 2], loc[si * 2 + 1], H, W);
+            in[k] = live && have && s[k].in_range;
+            o1[k] = lvl_off + ((int64_t)s[k].h_low * W + s[k].w_low) * pix_stride;
+            const bool ld = in[k] && ch;
+            v[k][0] = (ld && s[k].ok1) ? value[o1[k]] : (T)0;
+            v[k][1] = (ld && s[k].ok2) ? value[o1[k] + pix_stride] : (T)0;
+            v[k][2] = (ld && s[k].ok3) ? value[o1[k] + (int64_t)W * pix_stride] : (T)0;
+            v[k][3] = (ld && s[k].ok4) ? value[o1[k] + (int64_t)W * pix_stride + pix_stride] : (T)0;
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (p0 + k >= d.P) break;                       // uniform
+            const int64_t si = pair * LP + l * d.P + p0 + k;
+            T pa = 0, pw = 0, ph = 0;
+            if (__ballot(in[k])) {                           // wave-uniform (the reductions need every lane of the group)
+              if (in[k] && ch) {
+                const Sample<T>& q = s[k];
+                const T tgv = g * a[k];
+                const T w1 = q.hh * q.hw, w2 = q.hh * q.lw, w3 = q.lh * q.hw, w4 = q.lh * q.lw;
+                const int64_t o3 = o1[k] + (int64_t)W * pix_stride;
+                if (q.ok1) atomic_add(grad_value + o1[k], w1 * tgv);
+                if (q.ok2) atomic_add(grad_value + o1[k] + pix_stride, w2 * tgv);
+                if (q.ok3) atomic_add(grad_value + o3, w3 * tgv);
+                if (q.ok4) atomic_add(grad_value + o3 + pix_stride, w4 * tgv);
+                pa = g * (w1 * v[k][0] + w2 * v[k][1] + w3 * v[k][2] + w4 * v[k][3]);
+                pw = tgv * (q.hh * (v[k][1] - v[k][0]) + q.lh * (v[k][3] - v[k][2]));
+                ph = tgv * (q.hw * (v[k][2] - v[k][0]) + q.lw * (v[k][3] - v[k][1]));
+              }
+              pa = group_sum(pa);
+              pw = group_sum(pw);
+              ph = group_sum(ph);
+            }
+            if (live && lane == 0) {
+              grad_attn[si] = pa;
+              grad_loc[si * 2] = (T)W * pw;
+              grad_loc[si * 2 + 1] = (T)H * ph;
+            }
+          }
+        }
+      }
+      continue;
+    }
     for (int l = 0; l < d.L; ++l) {
       const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
       const int64_t lvl_off = (b * d.S + lsi[l]) * pix_stride + (int64_t)m * d.D;
