@@ -105,8 +105,32 @@ CASES = {
 }
 
 
+def mint_encoder_shaped(ref):
+    """An encoder-shaped call (num_query == spatial_size >= 1024, 32 channels, 4 levels x 4 points) with the model-like
+    locations of the bench (uninext_amd/workloads.py): the shape the window forward kernel and the tiled backward kernel
+    take.  Inputs are float32 values (run through the reference in float64), everything is stored as float32 to keep
+    the file small; the tests hold the float64 oracle to 1e-6 and the kernels to 1e-4 against it."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from uninext_amd import workloads
+    levels = ((24, 33), (12, 17), (6, 9), (3, 5))            # S = 1065
+    x = workloads.make_inputs("encoder", "model", batch=1, levels=levels, heads=2, seed=31, device="cpu")
+    value, loc, attn = x["value"].double(), x["loc"].double(), x["attn"].double()
+    value.requires_grad_(True)
+    loc.requires_grad_(True)
+    attn.requires_grad_(True)
+    out = ref.ms_deform_attn_core_pytorch(value, x["shapes"], loc, attn)
+    grad_out = torch.randn(out.shape, generator=torch.Generator().manual_seed(1031)).double()   # float32 values
+    gv, gl, ga = torch.autograd.grad(out, (value, loc, attn), grad_out)
+    f32 = lambda t: t.detach().float().numpy()
+    np.savez_compressed(os.path.join(HERE, "encshape_s1065_m2.npz"), value=f32(value), shapes=x["shapes"].numpy(),
+                        lsi=x["lsi"].numpy(), loc=f32(loc), attn=f32(attn), out=f32(out), grad_out=f32(grad_out),
+                        grad_value=f32(gv), grad_loc=f32(gl), grad_attn=f32(ga))
+    print(f"encshape_s1065_m2: out{tuple(out.shape)} |out|max={out.abs().max():.3e}")
+
+
 def main():
     ref = load_reference_func()
+    mint_encoder_shaped(ref)
     for name, (builder, kw) in CASES.items():
         value, shapes, loc, attn = builder(**kw)
         value, loc, attn = value.double(), loc.double(), attn.double()

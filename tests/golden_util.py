@@ -13,7 +13,7 @@ def _names():
 
 def golden_names():
     """MSDeformAttn operator fixtures (tests/golden/make_golden.py)."""
-    return [n for n in _names() if not n.startswith(("matcher_", "dynmask_", "patch_", "maskhead_", "enclayer_", "encstack_"))]
+    return [n for n in _names() if not n.startswith(("matcher_", "dynmask_", "patch_", "maskhead_", "enclayer_", "encstack_", "encshape_"))]
 
 
 def dynmask_names():

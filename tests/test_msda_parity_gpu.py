@@ -267,3 +267,40 @@ print("KERNELS", captured_kernel, eager_kernel, _lib.forward_locality()[0])
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     line = [l for l in res.stdout.splitlines() if l.startswith("KERNELS")][0].split()
     assert line[1] == "msda_fwd_lg3" and line[2] == "msda_fwd_win" and int(line[3]) == 1, line
+
+
+@pytest.mark.parametrize("variant", ["auto", "msda_fwd_win", "msda_fwd_lg3", "msda_fwd_lanegroup"])
+def test_encoder_shaped_reference_fixture_forward(variant, dev, api):
+    """Every kernel an encoder-shaped call can take, against the REFERENCE's own output for that shape
+    (tests/golden/encshape_s1065_m2.npz, minted by ms_deform_attn_core_pytorch in float64): abs 1e-4."""
+    from golden_util import load_golden
+    MSDA, lib = api
+    g = load_golden("encshape_s1065_m2")
+    x = {k: torch.from_numpy(g[k]).to(dev) for k in ("value", "shapes", "lsi", "loc", "attn")}
+    out = _fwd(MSDA, lib, x, variant)
+    if variant != "auto":
+        assert lib.last_kernel("forward") == variant
+    assert float(np.abs(out.cpu().numpy().reshape(g["out"].shape) - g["out"]).max()) < 1e-4
+
+
+@pytest.mark.parametrize("variant", ["auto", "msda_bwd_tiled", "msda_bwd_generic"])
+def test_encoder_shaped_reference_fixture_backward(variant, dev, api):
+    """The backward kernels on the same fixture (autograd through the reference's function in float64)."""
+    from golden_util import load_golden
+    MSDA, lib = api
+    g = load_golden("encshape_s1065_m2")
+    x = {k: torch.from_numpy(g[k]).to(dev) for k in ("value", "shapes", "lsi", "loc", "attn", "grad_out")}
+    lib.set_variant("backward", variant)
+    try:
+        gv, gl, ga = MSDA.ms_deform_attn_backward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], x["grad_out"], 64)
+    finally:
+        lib.set_variant("backward", "auto")
+    assert lib.last_kernel("backward") == ("msda_bwd_tiled" if variant == "auto" else variant)
+    assert float(np.abs(gv.cpu().numpy() - g["grad_value"]).max()) < 1e-4
+    assert float(np.abs(ga.cpu().numpy() - g["grad_attn"]).max()) < 2e-4       # float32 evaluation of the bilinear form
+    d = np.abs(gl.cpu().numpy() - g["grad_loc"])                                # [1, Lq, M, L, P, 2]
+    levels = g["shapes"].tolist()
+    for l, (h, w) in enumerate(levels):
+        # 1e-4 * max(W, H) (the gradient carries that factor); the fixture's grid_sample gradient and the CUDA formula pick
+        # different one-sided derivatives exactly on a cell edge -- generic locations: at most a handful of samples
+        assert float(np.quantile(d[:, :, :, l], 0.999)) < 1e-4 * max(h, w), (l, float(d[:, :, :, l].max()))

@@ -101,3 +101,24 @@ def test_oracle_gradcheck_against_autograd_random():
     assert max_abs(ogv, gv.numpy()) < 1e-11
     assert max_abs(ogl, gl.numpy()) < 1e-9
     assert max_abs(oga, ga.numpy()) < 1e-11
+
+
+def test_oracle_on_the_encoder_shaped_reference_fixture():
+    """tests/golden/encshape_s1065_m2.npz (make_golden.py: mint_encoder_shaped): an encoder-shaped call with model-like
+    locations, run through the reference in float64 and stored as float32.  The float64 oracle on the stored float32
+    inputs reproduces it to float32 round-off of the stored values."""
+    from golden_util import load_golden
+    from oracle import msda_oracle
+    import torch
+    g = load_golden("encshape_s1065_m2")
+    t = lambda k: torch.from_numpy(g[k]).double()
+    shapes, lsi = torch.from_numpy(g["shapes"]), torch.from_numpy(g["lsi"])
+    out = msda_oracle.forward(t("value"), shapes, lsi, t("loc"), t("attn"))
+    assert float(np.abs(out - g["out"]).max()) < 1e-6
+    gv, gl, ga = msda_oracle.backward(t("grad_out"), t("value"), shapes, lsi, t("loc"), t("attn"))
+    assert float(np.abs(gv - g["grad_value"]).max()) < 1e-5 * max(1.0, float(np.abs(g["grad_value"]).max()))
+    assert float(np.abs(ga - g["grad_attn"]).max()) < 1e-5 * max(1.0, float(np.abs(g["grad_attn"]).max()))
+    # grad_loc: the oracle follows the CUDA formula, the fixture grid_sample's autograd -- they agree away from cell
+    # edges (module docstring); model-like locations are generic, so a handful of edge cases at most
+    d = np.abs(gl - g["grad_loc"])
+    assert float(np.quantile(d, 0.999)) < 1e-4 * max(1.0, float(np.abs(g["grad_loc"]).max()))
