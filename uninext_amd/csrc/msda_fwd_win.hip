@@ -633,8 +633,11 @@ extern "C" int msda_debug_read_prof(void* dst, int nblocks) {
 #endif
 
 bool win_forward_ok(const Dims& d) {
+  // (the last condition keeps the work-item index, and item + 0.5, exact in float: the kernel splits it into (image,
+  // tile) with a reciprocal)
   return d.D == 32 && d.P == 4 && d.L == 4 && d.Lq == d.S && d.S >= 1024 &&
-         (int64_t)d.S * d.M * 128 < (int64_t)kOobOffset && d.N <= 65535;
+         (int64_t)d.S * d.M * 128 < (int64_t)kOobOffset && d.N <= 65535 &&
+         (int64_t)d.N * ((d.S + 127) / 128) < ((int64_t)1 << 22);
 }
 
 namespace {
