@@ -304,3 +304,29 @@ def test_encoder_shaped_reference_fixture_backward(variant, dev, api):
         # 1e-4 * max(W, H) (the gradient carries that factor); the fixture's grid_sample gradient and the CUDA formula pick
         # different one-sided derivatives exactly on a cell edge -- generic locations: at most a handful of samples
         assert float(np.quantile(d[:, :, :, l], 0.999)) < 1e-4 * max(h, w), (l, float(d[:, :, :, l].max()))
+
+
+@pytest.mark.parametrize("heads,batch", [(8, 5), (3, 3), (16, 1)])
+def test_encoder_kernels_on_other_batch_sizes_and_head_counts(heads, batch, dev, api):
+    """The window forward and the tiled backward index work items by (image, head, tile): odd batch sizes and head counts
+    that are not the XCD count, every query against the C oracle (quarter-scale R50 pyramid, model-like locations)."""
+    from oracle import msda_oracle
+    from uninext_amd import workloads
+    MSDA, lib = api
+    levels = ((25, 42), (13, 21), (7, 11), (4, 6))
+    x = workloads.make_inputs("encoder", "model", batch=batch, levels=levels, heads=heads, seed=50 + heads, device=dev)
+    ref = msda_oracle.forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
+    out = _fwd(MSDA, lib, x, "msda_fwd_win")
+    assert lib.last_kernel("forward") == "msda_fwd_win"
+    assert float(np.abs(out.cpu().numpy().astype(np.float64) - ref).max()) < 1e-4
+    S = x["value"].shape[1]
+    go = torch.randn(batch, S, heads * 32, generator=torch.Generator().manual_seed(7)).to(dev)
+    gv, gl, ga = MSDA.ms_deform_attn_backward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], go, 64)
+    assert lib.last_kernel("backward") == "msda_bwd_tiled"
+    tgv, _, tga = msda_oracle.backward(go.double(), x["value"].double(), x["shapes"], x["lsi"], x["loc"].double(), x["attn"].double())
+    ogv, ogl, oga = msda_oracle.backward(go, x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
+    assert float(np.abs(gv.cpu().numpy().astype(np.float64) - tgv).max()) < 1e-4
+    assert float(np.abs(ga.cpu().numpy().astype(np.float64) - tga).max()) < max(1e-4, 2.0 * float(np.abs(oga - tga).max()))
+    d_gl = np.abs(gl.cpu().numpy().astype(np.float64) - ogl)
+    for l, (h, w) in enumerate(levels):
+        assert float(d_gl[:, :, :, l].max()) < 1e-4 * max(h, w)

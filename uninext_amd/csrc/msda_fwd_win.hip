@@ -448,13 +448,16 @@ __device__ __forceinline__ void win_body(const float* __restrict__ value, const 
           const bool t_ok = has && fy0 >= 0, b_ok = has && fy0 + 1 <= fH - 1, l_ok = fx0 >= 0, r_ok = fx0 + 1 <= fW - 1;
           const float wt = (1.f - lh) * fav, wb = lh * fav;
           f.w1 = wt * (1.f - lw); f.w2 = wt * lw; f.w3 = wb * (1.f - lw); f.w4 = wb * lw;
-          // 24-bit multiply-adds (pixel index < 2^24, pitch < 2^24; a negative fy0 / fx0 only occurs on corners that are
-          // switched off below)
-          const uint32_t off = mad_u24(mad_u24((uint32_t)fy0, (uint32_t)fW, (uint32_t)(fS + fx0)), pixB, c0);
+          // 24-bit multiply-adds (pixel index < 2^24, pitch < 2^24) on the CLAMPED top-left pixel: with fy0 or fx0 = -1 the
+          // live corners sit in row / column 0, and a 24-bit product of a negative index is not what a 32-bit one wraps
+          // to (it differed by 2^31 for odd head counts: the live corners of such samples were dropped)
+          const int cy = max(fy0, 0), cx = max(fx0, 0);
+          const uint32_t off = mad_u24(mad_u24((uint32_t)cy, (uint32_t)fW, (uint32_t)(fS + cx)), pixB, c0);
+          const uint32_t dx = fx0 >= 0 ? pixB : 0u, dy = fy0 >= 0 ? rowG : 0u;   // step to the right / bottom neighbour
           const uint32_t o1 = (t_ok && l_ok) ? off : kOobOffset;
-          const uint32_t o2 = (t_ok && r_ok) ? off + pixB : kOobOffset;
-          const uint32_t o3 = (b_ok && l_ok) ? off + rowG : kOobOffset;
-          const uint32_t o4 = (b_ok && r_ok) ? off + rowG + pixB : kOobOffset;
+          const uint32_t o2 = (t_ok && r_ok) ? off + dx : kOobOffset;
+          const uint32_t o3 = (b_ok && l_ok) ? off + dy : kOobOffset;
+          const uint32_t o4 = (b_ok && r_ok) ? off + dy + dx : kOobOffset;
           f.d1a = buffer_load_f32x4(vsrc, o1, hoff); f.d1b = buffer_load_f32x4(vsrc, o1 ^ 64u, hoff);
           f.d2a = buffer_load_f32x4(vsrc, o2, hoff); f.d2b = buffer_load_f32x4(vsrc, o2 ^ 64u, hoff);
           f.d3a = buffer_load_f32x4(vsrc, o3, hoff); f.d3b = buffer_load_f32x4(vsrc, o3 ^ 64u, hoff);
