@@ -330,3 +330,21 @@ def test_encoder_kernels_on_other_batch_sizes_and_head_counts(heads, batch, dev,
     d_gl = np.abs(gl.cpu().numpy().astype(np.float64) - ogl)
     for l, (h, w) in enumerate(levels):
         assert float(d_gl[:, :, :, l].max()) < 1e-4 * max(h, w)
+
+
+@pytest.mark.parametrize("heads", [1, 3, 5, 7])
+@pytest.mark.parametrize("flavour", ["uniform", "wide"])
+def test_window_forward_far_path_with_odd_head_counts(heads, flavour, dev, api):
+    """The far path of msda_fwd_win addresses `value` with 24-bit multiply-adds; its offsets for samples whose top-left
+    corner lies at row / column -1 once depended on the head count being even.  Far-heavy flavours, odd head counts, two
+    pyramids, every query against the C oracle."""
+    from oracle import msda_oracle
+    from uninext_amd import workloads
+    MSDA, lib = api
+    kw = dict(flavour="model", offset_sigma=6.0) if flavour == "wide" else dict(flavour=flavour)
+    for levels in (ODD_PYRAMIDS[2], ODD_PYRAMIDS[4]):
+        x = workloads.make_inputs("encoder", batch=2, levels=levels, heads=heads, seed=60 + heads, device=dev, **kw)
+        out = _fwd(MSDA, lib, x, "msda_fwd_win")
+        assert lib.last_kernel("forward") == "msda_fwd_win"
+        ref = msda_oracle.forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
+        assert float(np.abs(out.cpu().numpy().astype(np.float64) - ref).max()) < 1e-4, (levels, heads)
