@@ -188,6 +188,8 @@ const char* msda_hip_last_kernel(int which);
  * refresh the report.  The choice never changes a result beyond fp32 summation order.  MSDA_HIP_FWD_ADAPTIVE=0 in
  * the environment pins variant 0 to the gather kernel.
  *
+ * The fused entry points (msda_hip_forward_fused[_hm]_f32) choose between the same two kernels in the same way.
+ *
  * msda_hip_forward_locality: number of reports received so far on the current device (0: none yet; the report of a
  * launch lands when that launch completes) and, in *far_fraction (may be NULL), the far fraction of the latest one.
  */

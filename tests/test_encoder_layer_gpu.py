@@ -105,7 +105,7 @@ def test_layer_full_size_routes_agree(dev):
     sh, lsi = workloads.level_tensors(levels, dev)
     with torch.no_grad():
         fast = layer(src, pos, ref, sh, lsi, None)
-        assert _lib.last_kernel("forward") == "msda_fwd_lg3_fused"
+        assert _lib.last_kernel("forward") in ("msda_fwd_lg3_fused", "msda_fwd_win_fused")
         MSDeformAttn.fast_linear = False
         try:
             q = src + pos

@@ -348,3 +348,50 @@ def test_window_forward_far_path_with_odd_head_counts(heads, flavour, dev, api):
         assert lib.last_kernel("forward") == "msda_fwd_win"
         ref = msda_oracle.forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
         assert float(np.abs(out.cpu().numpy().astype(np.float64) - ref).max()) < 1e-4, (levels, heads)
+
+
+@pytest.mark.parametrize("head_major", [False, True])
+@pytest.mark.parametrize("ref_dim", [2, 4])
+def test_fused_encoder_forward_window_and_gather_kernels(ref_dim, head_major, dev, api):
+    """msda_hip_forward_fused[_hm]_f32 on an encoder-shaped call: the prologue of MSDeformAttn.forward
+    (ops/modules/ms_deform_attn.py:99-112: softmax, loc = ref + off / (W, H) or the box form) folded into the window
+    kernel and into the gather kernel, both value layouts, against the C oracle fed with the PyTorch prologue."""
+    import torch.nn.functional as F
+    from oracle import msda_oracle
+    from uninext_amd import ext, workloads
+    MSDA, lib = api
+    levels = ((25, 42), (13, 21), (7, 11), (4, 6))
+    S = sum(h * w for h, w in levels)
+    N, M, L, P = 2, 8, 4, 4
+    g = torch.Generator().manual_seed(70 + ref_dim)
+    value = torch.randn(N, S, M, 32, generator=g).to(dev)
+    offsets = torch.randn(N, S, M * L * P * 2, generator=g) * 2.0
+    offsets[:, ::37] *= 8.0                                       # some queries sample far away (the far path)
+    offsets = offsets.to(dev)
+    logits = (torch.randn(N, S, M * L * P, generator=g) * 3.0).to(dev)
+    logits[0, 1, :16] = 80.0                                      # equal large logits: softmax must not overflow
+    sh, lsi = workloads.level_tensors(levels, dev)
+    ref_xy = workloads.encoder_reference_points(levels, dev)[None, :, None, :].expand(N, S, L, 2)
+    if ref_dim == 2:
+        ref = ref_xy.contiguous()
+    else:
+        wh = (torch.rand(N, S, L, 2, generator=g) * 0.2 + 0.02).to(dev)
+        ref = torch.cat([ref_xy, wh], -1).contiguous()
+    off = offsets.view(N, S, M, L, P, 2)
+    attn = F.softmax(logits.view(N, S, M, L * P), -1).view(N, S, M, L, P)
+    if ref_dim == 2:
+        norm = torch.stack([sh[..., 1], sh[..., 0]], -1)
+        loc = ref[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+    else:
+        loc = ref[:, :, None, :, None, :2] + off / P * ref[:, :, None, :, None, 2:] * 0.5
+    want = msda_oracle.forward(value, sh, lsi, loc.contiguous(), attn.contiguous())
+    v_in = value.permute(0, 2, 1, 3).contiguous() if head_major else value
+    for variant, kernel in (("msda_fwd_win", "msda_fwd_win_fused"), ("msda_fwd_lg3", "msda_fwd_lg3_fused")):
+        lib.set_variant("forward", variant)
+        try:
+            out = ext.ms_deform_attn_forward_fused(v_in, sh, lsi, ref, offsets, logits, P, value_head_major=head_major)
+        finally:
+            lib.set_variant("forward", "auto")
+        assert lib.last_kernel("forward") == kernel
+        err = float(np.abs(out.cpu().numpy().astype(np.float64) - want).max())
+        assert err < 1e-4, (variant, err)

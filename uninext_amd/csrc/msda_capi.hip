@@ -140,7 +140,7 @@ static int forward_fused_impl(const float* value, int head_major, const int64_t*
   if (!value || !spatial_shapes || !level_start_index || !reference_points || !sampling_offsets || !attn_logits || !output)
     return fail(MSDA_ERR_NULL_POINTER, "null pointer argument");
   const char* name = "";
-  const int rc = msda::launch_forward_fused(value, head_major, spatial_shapes, level_start_index, reference_points,
+  const int rc = msda::launch_forward_fused(current_variant(0), value, head_major, spatial_shapes, level_start_index, reference_points,
                                             ref_dim, sampling_offsets, attn_logits, d, output, (hipStream_t)stream, &name);
   g_last_kernel[0].store(name, std::memory_order_relaxed);
   return finish(rc, "msda_hip_forward_fused");

@@ -104,7 +104,7 @@ enum Variant { kAuto = 0, kGeneric = 1, kLaneGroup = 2, kTiled = 3, kTiledL0 = 4
 // msda_fwd.hip: forward with the MSDeformAttn prologue (softmax + sampling locations) fused in.
 bool fused_forward_ok(const Dims& d, int ref_dim);
 bool fused_forward_hm_ok(const Dims& d, int ref_dim);   // head-major value: encoder-sized calls only
-int launch_forward_fused(const float* value, int head_major, const int64_t* shapes, const int64_t* lsi,
+int launch_forward_fused(int variant, const float* value, int head_major, const int64_t* shapes, const int64_t* lsi,
                          const float* ref_points, int ref_dim, const float* offsets, const float* logits, const Dims& d,
                          float* out, hipStream_t stream, const char** kernel_name);
 
@@ -117,6 +117,9 @@ int launch_backward_tiled(const float* grad_out, const float* value, const int64
 // msda_fwd_win.hip: encoder forward with LDS windows on all four levels (fp32, D = 32, L = P = 4, Lq == S).
 bool win_forward_ok(const Dims& d);
 bool win_forward_auto(const Dims& d, hipStream_t stream);   // auto dispatch: take the window kernel for this call?
+int launch_forward_win_fused(const float* value, int head_major, const int64_t* shapes, const int64_t* lsi,
+                             const float* ref_points, int ref_dim, const float* offsets, const float* logits, const Dims& d,
+                             float* out, hipStream_t stream);
 int forward_locality(double* far_fraction);      // reports so far (0: none yet) and the last one's far fraction
 int launch_forward_win(const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc, const float* attn,
                        const Dims& d, float* out, hipStream_t stream);

@@ -310,10 +310,16 @@ static int launch_lg3_t(const float* value, const int64_t* shapes, const int64_t
 
 bool fused_forward_hm_ok(const Dims& d, int ref_dim) { return fused_forward_ok(d, ref_dim) && lg3_ok(d); }
 
-int launch_forward_fused(const float* value, int head_major, const int64_t* shapes, const int64_t* lsi,
+int launch_forward_fused(int variant, const float* value, int head_major, const int64_t* shapes, const int64_t* lsi,
                          const float* ref_points, int ref_dim, const float* offsets, const float* logits, const Dims& d,
                          float* out, hipStream_t stream, const char** kernel_name) {
   static const bool use_lg3 = !(std::getenv("MSDA_HIP_FUSED_LG3") && std::getenv("MSDA_HIP_FUSED_LG3")[0] == '0');
+  // encoder-shaped calls: the LDS-window kernel with the prologue folded in while the samples are local (variant 0
+  // follows the locality report like the operator does; variants 9 / 7 pin the window / the gather kernel)
+  if (win_forward_ok(d) && (variant == kWin || (variant == kAuto && win_forward_auto(d, stream)))) {
+    *kernel_name = "msda_fwd_win_fused";
+    return launch_forward_win_fused(value, head_major, shapes, lsi, ref_points, ref_dim, offsets, logits, d, out, stream);
+  }
   if (lg3_ok(d) && (use_lg3 || head_major)) {   // encoder-sized calls: the lg3 structure with the prologue folded in
     *kernel_name = "msda_fwd_lg3_fused";
     return ref_dim == 2 ? launch_lg3_t<2>(value, shapes, lsi, offsets, logits, ref_points, d, head_major, out, stream)

@@ -146,10 +146,14 @@ __device__ __forceinline__ int stat_shift(int workgroups) {
 // STAT: this workgroup contributes to the locality statistic of the launch (1 workgroup in 16 does: the kernel below
 // runs one of two copies of this body, so that the other 15 keep the register allocation of the plain kernel -- with
 // the counting compiled into every workgroup the extra spills cost 5 us).
-template <int DMA_AUX, bool STAT>   // DMA_AUX: cache policy bits of the window DMA (0 = default, 2 = non-temporal)
+// REFD: 0 = the operator (loc = normalised sampling locations, attn = softmaxed weights); 2 / 4 = the module's
+// elementwise prologue folded in (ops/modules/ms_deform_attn.py:99-112): loc = raw sampling offsets, attn = raw logits
+// (same layouts), ref_points [N, Lq, 4 levels, REFD]; head_major: value is [N, M, S, 32] (linear_hip_packed_hm_f32).
+template <int DMA_AUX, bool STAT, int REFD>   // DMA_AUX: cache policy bits of the window DMA (0 = default, 2 = non-temporal)
 __device__ __forceinline__ void win_body(const float* __restrict__ value, const int64_t* __restrict__ shapes,
                                          const int64_t* __restrict__ lsi, const float* __restrict__ loc,
-                                         const float* __restrict__ attn, const Dims& d, float* __restrict__ out) {
+                                         const float* __restrict__ attn, const Dims& d, float* __restrict__ out,
+                                         const float* __restrict__ ref_points, const bool head_major) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Meta& mt = *reinterpret_cast<Meta*>(smem + kMetaOff);
   const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -191,8 +195,8 @@ __device__ __forceinline__ void win_body(const float* __restrict__ value, const 
   if (tid >= 32 && tid < 35) mt.stat[tid - 32] = 0;
   __syncthreads();                                         // the sums are zero before any wave adds to them
 
-  const uint32_t pixB = (uint32_t)M * 128u;
-  const uint32_t hoff = (uint32_t)m * 128u;
+  const uint32_t pixB = head_major ? 128u : (uint32_t)M * 128u;   // bytes from a pixel of head m to the next one
+  const uint32_t hoff = head_major ? 0u : (uint32_t)m * 128u;
 
   for (int item = kk, it = 0; item < nitems; item += K, ++it) {
 #ifdef MSDA_WIN_PROF
@@ -207,13 +211,17 @@ __device__ __forceinline__ void win_body(const float* __restrict__ value, const 
     const float* const loc_img = loc + pair_img * 32;       // uniform bases: per-lane offsets stay 32-bit (S * M * 128 < 2^31)
     const float* const attn_img = attn + pair_img * 16;
     float* const out_img = out + pair_img * 32;
+    const float* const ref_img = REFD ? ref_points + (int64_t)b * d.Lq * (4 * REFD) : nullptr;
     const __amdgpu_buffer_rsrc_t vsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(value) + (int64_t)b * d.S * M * 32, 0, (int)((uint32_t)d.S * pixB), 0x00020000);
+        const_cast<float*>(value) + (head_major ? ((int64_t)b * M + m) * d.S * 32 : (int64_t)b * d.S * M * 32), 0,
+        (int)((uint32_t)d.S * pixB), 0x00020000);
     int (*const sums)[4] = mt.sum[it & 1];
     int nrest;                                              // queries of levels 1..3 of this item, and where they start
     int e1, e2;
     f32x4 lcA, lcB, at;                                     // lane k: the four points of level k -- 32 B + 16 B
+    f32x4 rf = {0.f, 0.f, 0.f, 0.f};                        // REFD: the query's reference point / box on level k
     uint32_t pair;                                          // (query, head) pair within the image
+    uint32_t qidx = 0;                                      // REFD: the query itself
     bool live;
     auto fetch = [&](int kq) __attribute__((always_inline)) {
       lcA = lcB = at = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -222,6 +230,12 @@ __device__ __forceinline__ void win_body(const float* __restrict__ value, const 
         lcA = __builtin_nontemporal_load(lp);
         lcB = __builtin_nontemporal_load(lp + 1);
         at = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(attn_img + (pair * 16u + 4u * (uint32_t)kq)));
+        if constexpr (REFD == 2) {
+          const msda::f32x2 r2 = *reinterpret_cast<const msda::f32x2*>(ref_img + (qidx * 8u + 2u * (uint32_t)kq));
+          rf[0] = r2[0]; rf[1] = r2[1];
+        } else if constexpr (REFD == 4) {
+          rf = *reinterpret_cast<const f32x4*>(ref_img + (qidx * 16u + 4u * (uint32_t)kq));
+        }
       }
     };
     {
@@ -248,7 +262,8 @@ __device__ __forceinline__ void win_body(const float* __restrict__ value, const 
       // round 0 = the level-0 queries of the tile, wave = tile row, quad = tile column (no division)
       live = pq < (int)qb<0>((uint32_t)nx) && wv < (int)qb<0>((uint32_t)(ye - ys));
       const int q = lvS[0] + ((int)qb<0>((uint32_t)ys) + wv) * lvW[0] + (int)qb<0>((uint32_t)xs) + pq;
-      pair = mad_u24((uint32_t)(live ? q : 0), (uint32_t)M, (uint32_t)m);
+      qidx = (uint32_t)(live ? q : 0);
+      pair = mad_u24(qidx, (uint32_t)M, (uint32_t)m);
       fetch(kq);
     }
     WIN_STAMP(1);
@@ -273,11 +288,30 @@ __device__ __forceinline__ void win_body(const float* __restrict__ value, const 
       float sa[4];
       bool inr[4];
       int x0[4], y0[4];
+      if constexpr (REFD != 0) {
+        // softmax over the pair's 16 logits: four per lane, the quad finishes it with DPP (v_rcp_f32: 1 ulp on the weights)
+        float mx = fmaxf(fmaxf(at[0], at[1]), fmaxf(at[2], at[3]));
+        mx = fmaxf(mx, __uint_as_float((uint32_t)dppi<0xB1>((int)__float_as_uint(mx))));
+        mx = fmaxf(mx, __uint_as_float((uint32_t)dppi<0x4E>((int)__float_as_uint(mx))));
+        at[0] = __expf(at[0] - mx); at[1] = __expf(at[1] - mx); at[2] = __expf(at[2] - mx); at[3] = __expf(at[3] - mx);
+        float sm_ = (at[0] + at[1]) + (at[2] + at[3]);
+        sm_ += __uint_as_float((uint32_t)dppi<0xB1>((int)__float_as_uint(sm_)));
+        sm_ += __uint_as_float((uint32_t)dppi<0x4E>((int)__float_as_uint(sm_)));
+        const float inv = __builtin_amdgcn_rcpf(sm_);
+        at[0] *= inv; at[1] *= inv; at[2] *= inv; at[3] *= inv;
+      }
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         const v2f l2 = p == 0 ? v2f{lcA[0], lcA[1]} : p == 1 ? v2f{lcA[2], lcA[3]} : p == 2 ? v2f{lcB[0], lcB[1]} : v2f{lcB[2], lcB[3]};
         sa[p] = at[p];
-        xy[p] = __builtin_elementwise_fma(l2, fWH, v2f{-0.5f, -0.5f});
+        if constexpr (REFD == 0) {
+          xy[p] = __builtin_elementwise_fma(l2, fWH, v2f{-0.5f, -0.5f});
+        } else if constexpr (REFD == 2) {   // loc = ref + off / (W, H):  loc * (W, H) - 0.5 = ref * (W, H) + (off - 0.5)
+          xy[p] = __builtin_elementwise_fma(v2f{rf[0], rf[1]}, fWH, l2 - v2f{0.5f, 0.5f});
+        } else {                            // loc = ref_xy + off / P * ref_wh * 0.5  (P = 4)
+          const v2f lc = __builtin_elementwise_fma(l2, v2f{rf[2], rf[3]} * 0.125f, v2f{rf[0], rf[1]});
+          xy[p] = __builtin_elementwise_fma(lc, fWH, v2f{-0.5f, -0.5f});
+        }
         fl[p] = v2f{floorf(xy[p].x), floorf(xy[p].y)};
         inr[p] = live && (xy[p].y > -1.f) && (xy[p].x > -1.f) && (xy[p].y < fWH.y) && (xy[p].x < fWH.x);
         x0[p] = inr[p] ? (int)fl[p].x : 0;
@@ -522,7 +556,8 @@ __device__ __forceinline__ void win_body(const float* __restrict__ value, const 
         const int Wq = qWS.x, Sq = qWS.y;
         const int yy = (int)(((float)j + 0.5f) * __builtin_amdgcn_rcpf((float)max(ge.z, 1)));
         const uint32_t qn = mad_u24((uint32_t)(ge.y + yy), (uint32_t)Wq, (uint32_t)(Sq + ge.x + j)) - mad_u24((uint32_t)yy, (uint32_t)ge.z, 0u);
-        pair = mad_u24(live ? qn : 0u, (uint32_t)M, (uint32_t)m);
+        qidx = live ? qn : 0u;
+        pair = mad_u24(qidx, (uint32_t)M, (uint32_t)m);
         fetch(k);
       }
 
@@ -611,21 +646,36 @@ __device__ __forceinline__ void win_body(const float* __restrict__ value, const 
   }
 }
 
+// which copy of the body a workgroup runs: the counting one for every 2^shift-th workgroup of a head
+__device__ __forceinline__ bool win_sampled(const int64_t* __restrict__ shapes, const Dims& d) {
+  const int M = d.M, kk = blockIdx.x / M, K = gridDim.x / M;
+  const int TY = ((int)shapes[0] + kTH - 1) / kTH, TX = ((int)shapes[1] + kTW - 1) / kTW;
+  const int nitems = d.N * TY * TX;
+  return (kk & ((1 << stat_shift(M * min(K, nitems))) - 1)) == 0;
+}
+
 template <int DMA_AUX, bool STAT>
 __global__ void __launch_bounds__(kT, 4)
 msda_fwd_win(const float* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
              const float* __restrict__ loc, const float* __restrict__ attn, Dims d, float* __restrict__ out) {
-  if (STAT) {
-    // sampled workgroups: every 2^shift-th of a head (the same expressions as in the body)
-    const int M = d.M, kk = blockIdx.x / M, K = gridDim.x / M;
-    const int TY = ((int)shapes[0] + kTH - 1) / kTH, TX = ((int)shapes[1] + kTW - 1) / kTW;
-    const int nitems = d.N * TY * TX;
-    if ((kk & ((1 << stat_shift(M * min(K, nitems))) - 1)) == 0) {
-      win_body<DMA_AUX, true>(value, shapes, lsi, loc, attn, d, out);
-      return;
-    }
+  if (STAT && win_sampled(shapes, d)) {
+    win_body<DMA_AUX, true, 0>(value, shapes, lsi, loc, attn, d, out, nullptr, false);
+    return;
   }
-  win_body<DMA_AUX, false>(value, shapes, lsi, loc, attn, d, out);
+  win_body<DMA_AUX, false, 0>(value, shapes, lsi, loc, attn, d, out, nullptr, false);
+}
+
+// the module's inference path: prologue folded in (REFD = 2 / 4), value in the reference or the head-major layout
+template <bool STAT, int REFD>
+__global__ void __launch_bounds__(kT, 4)
+msda_fwd_win_fused(const float* __restrict__ value, int head_major, const int64_t* __restrict__ shapes,
+                   const int64_t* __restrict__ lsi, const float* __restrict__ ref_points, const float* __restrict__ offsets,
+                   const float* __restrict__ logits, Dims d, float* __restrict__ out) {
+  if (STAT && win_sampled(shapes, d)) {
+    win_body<0, true, REFD>(value, shapes, lsi, offsets, logits, d, out, ref_points, head_major != 0);
+    return;
+  }
+  win_body<0, false, REFD>(value, shapes, lsi, offsets, logits, d, out, ref_points, head_major != 0);
 }
 
 #ifdef MSDA_WIN_PROF
@@ -745,6 +795,23 @@ int launch_forward_win(const float* value, const int64_t* shapes, const int64_t*
   if (K < 1) K = 1;
   const dim3 grid((unsigned)(d.M * K), 1u);
   hipLaunchKernelGGL(kern, grid, dim3(kT), kLdsBytes, stream, value, shapes, lsi, loc, attn, d, out);
+  return (int)hipGetLastError();
+}
+
+int launch_forward_win_fused(const float* value, int head_major, const int64_t* shapes, const int64_t* lsi,
+                             const float* ref_points, int ref_dim, const float* offsets, const float* logits, const Dims& d,
+                             float* out, hipStream_t stream) {
+  static std::atomic<uint64_t> lds_opted_in[4] = {{0}, {0}, {0}, {0}};
+  static const bool stat_env = !(std::getenv("MSDA_WIN_STAT") && std::getenv("MSDA_WIN_STAT")[0] == '0');
+  const bool stat = stat_env && locality_state(stream) != nullptr;
+  const auto kern = ref_dim == 2 ? (stat ? msda_fwd_win_fused<true, 2> : msda_fwd_win_fused<false, 2>)
+                                 : (stat ? msda_fwd_win_fused<true, 4> : msda_fwd_win_fused<false, 4>);
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), kLdsBytes, lds_opted_in[(ref_dim == 2 ? 0 : 2) + (stat ? 1 : 0)]))
+    return rc;
+  int K = d.N * ((d.S + 127) / 128);                        // as in launch_forward_win
+  if (K < 1) K = 1;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(d.M * K), 1u), dim3(kT), kLdsBytes, stream, value, head_major, shapes, lsi,
+                     ref_points, offsets, logits, d, out);
   return (int)hipGetLastError();
 }
 
