@@ -57,6 +57,17 @@ int linear_hip_packed_ex_f32(const float* x, const float* x_add, const void* pac
                              float* out, void* stream);
 
 /*
+ * Two Linear layers on the same input as ONE product: W is the row-wise concatenation [W_a; W_b] packed as a
+ * [out_features, in_features] weight, bias the concatenation of the two biases (or NULL); columns [0, split_col) are
+ * written to out_a [rows, split_col], the rest to out_b [rows, out_features - split_col].  MSDeformAttn.forward
+ * computes sampling_offsets(query) and attention_weights(query) from the same query (ops/modules/ms_deform_attn.py:
+ * 99-100): one pass over query (+ x_add = the positional embedding) instead of two.  split_col must be a multiple of
+ * 128.  Every output element is the same sum of products as with the two separate calls.
+ */
+int linear_hip_packed_split_f32(const float* x, const float* x_add, const void* packed, const float* bias, long long rows,
+                                int in_features, int out_features, int split_col, float* out_a, float* out_b, void* stream);
+
+/*
  * Linear followed by the residual add and LayerNorm of the transformer layer, in the Linear's epilogue:
  *     out[m, :] = LayerNorm(residual[m, :] + bias + x[m, :] W^T) * gamma + beta
  * (`src = src + dropout(linear2(...)); src = norm2(src)` and the attention's output_proj + norm1,

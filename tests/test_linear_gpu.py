@@ -238,3 +238,24 @@ def test_fused_ffn_rejects_unsupported(dev):
         ext.ffn_packed(x, p1, None, p2, None, 192)
     with pytest.raises(RuntimeError):
         ext.ffn_packed(x, p1, None, p2, None, 256)   # packed sizes do not match d_ffn
+
+
+@pytest.mark.parametrize("rows,with_add", [(44446, True), (130, False), (64, True)])
+def test_two_output_linear_equals_the_two_separate_calls(rows, with_add, dev):
+    """linear_hip_packed_split_f32: sampling_offsets and attention_weights of MSDeformAttn (256 -> 256 and 256 -> 128) as
+    one product with two outputs.  Same packed arithmetic per element: bitwise the two separate calls."""
+    from uninext_amd import ext
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, 256, generator=g).to(dev)
+    xa = torch.randn(rows, 256, generator=g).to(dev) * 0.3 if with_add else None
+    wa, wb = (torch.randn(256, 256, generator=g) / 16).to(dev), (torch.randn(128, 256, generator=g) / 16).to(dev)
+    ba, bb = torch.randn(256, generator=g).to(dev), torch.randn(128, generator=g).to(dev)
+    pa, pb = ext.linear_pack_weight(wa), ext.linear_pack_weight(wb)
+    pab = ext.linear_pack_weight(torch.cat([wa, wb], 0).contiguous())
+    oa = ext.linear_packed_forward(x, pa, 256, ba, x_add=xa)
+    ob = ext.linear_packed_forward(x, pb, 128, bb, x_add=xa)
+    sa, sb = ext.linear_packed_split_forward(x, pab, 256, 384, torch.cat([ba, bb]).contiguous(), xa)
+    assert sa.shape == oa.shape and sb.shape == ob.shape
+    assert torch.equal(sa, oa) and torch.equal(sb, ob)
+    with pytest.raises(RuntimeError):
+        ext.linear_packed_split_forward(x, pab, 100, 384, None, xa)          # split column not a multiple of 128

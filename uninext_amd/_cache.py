@@ -10,6 +10,8 @@ the version counter does not see are handled explicitly:
 """
 import weakref
 
+import torch
+
 
 def tensor_version(t):
     """`t._version`, or -1 for inference tensors (no version counter; `_version` raises on them)."""
@@ -27,10 +29,32 @@ def packed_weight(module, pack_fn):
     return cache[1]
 
 
+def packed_weight_pair(owner, lin_a, lin_b, pack_fn):
+    """(packed copy of the row-wise concatenation [lin_a.weight; lin_b.weight], concatenated biases or None), cached on
+    `owner` and rebuilt when either parameter changes -- two Linear layers on the same input run as one product."""
+    ws = (lin_a.weight, lin_b.weight, lin_a.bias, lin_b.bias)
+    key = tuple((t.data_ptr(), tensor_version(t), str(t.device), tuple(t.shape)) if t is not None else None for t in ws)
+    cache = owner.__dict__.get("_msda_packed_pair")
+    if cache is None or cache[0] != key:
+        w = torch.cat([lin_a.weight.detach(), lin_b.weight.detach()], 0).contiguous()
+        if lin_a.bias is not None and lin_b.bias is not None:
+            b = torch.cat([lin_a.bias.detach(), lin_b.bias.detach()], 0).contiguous()
+        elif lin_a.bias is None and lin_b.bias is None:
+            b = None
+        else:
+            zeros = lambda lin: torch.zeros(lin.weight.shape[0], dtype=lin.weight.dtype, device=lin.weight.device)
+            b = torch.cat([lin_a.bias.detach() if lin_a.bias is not None else zeros(lin_a),
+                           lin_b.bias.detach() if lin_b.bias is not None else zeros(lin_b)], 0).contiguous()
+        cache = (key, (pack_fn(w), b))
+        owner.__dict__["_msda_packed_pair"] = cache
+    return cache[1]
+
+
 def invalidate_packed(root):
     """Drop every packed-weight cache under `root` (an nn.Module); the next inference call re-packs."""
     for m in root.modules():
         m.__dict__.pop("_msda_packed", None)
+        m.__dict__.pop("_msda_packed_pair", None)
 
 
 class CachedModuleMixin:

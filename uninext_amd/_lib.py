@@ -22,7 +22,7 @@ DYNMASK_EXPORTS = ("dynmask_hip_forward_f32", "aligned_bilinear_hip_f32", "dynma
 PATCH_EMBED_EXPORTS = ("patch_embed_hip_f32", "patch_embed_hip_packed_weight_bytes", "patch_embed_hip_pack_weight_f32",
                        "patch_embed_hip_packed_f32")                           # include/patch_embed_hip.h
 LINEAR_EXPORTS = ("linear_hip_packed_weight_bytes", "linear_hip_pack_weight_f32", "linear_hip_packed_f32",
-                  "linear_hip_packed_hm_f32", "linear_hip_packed_ex_f32", "linear_hip_packed_ln_f32",
+                  "linear_hip_packed_hm_f32", "linear_hip_packed_ex_f32", "linear_hip_packed_split_f32", "linear_hip_packed_ln_f32",
                   "linear_hip_packed_ffn_f32")   # include/linear_hip.h
 LAYERNORM_EXPORTS = ("add_layernorm_hip_f32",)                                 # include/layernorm_hip.h
 LSAP_EXPORTS = ("lsap_hip_workspace_bytes", "lsap_hip_f32", "lsap_hip_batch_f32")   # include/lsap_hip.h
@@ -64,6 +64,8 @@ def load():
     lib.linear_hip_packed_hm_f32.restype = i
     lib.linear_hip_packed_ex_f32.argtypes = [p, p, p, p, p, ctypes.c_longlong, i, i, i, p, p]
     lib.linear_hip_packed_ex_f32.restype = i
+    lib.linear_hip_packed_split_f32.argtypes = [p, p, p, p, ctypes.c_longlong, i, i, i, p, p, p]
+    lib.linear_hip_packed_split_f32.restype = i
     lib.linear_hip_packed_ln_f32.argtypes = [p, p, p, p, p, p, ctypes.c_float, ctypes.c_longlong, i, i, p, p]
     lib.linear_hip_packed_ln_f32.restype = i
     lib.linear_hip_packed_ffn_f32.argtypes = [p, p, p, p, p, p, p, p, ctypes.c_float, i, ctypes.c_longlong, i, i, p, p]

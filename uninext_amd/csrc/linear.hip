@@ -148,7 +148,8 @@ template <int TJ, int BM, bool ADD, int WM, bool LN = false>   // ADD: the input
 __global__ void __launch_bounds__(kThreads, 2)
 linear_packed(const float* __restrict__ x, const float* __restrict__ x2, const uint32_t* __restrict__ packed,
               const float* __restrict__ bias, const uint8_t* __restrict__ row_mask, long long M, int K, int N, int n_pad,
-              int hm_rows, int act, float* __restrict__ out, LnArgs ln = LnArgs{nullptr, nullptr, nullptr, 0.f}) {
+              int hm_rows, int act, float* __restrict__ out, LnArgs ln = LnArgs{nullptr, nullptr, nullptr, 0.f},
+              float* __restrict__ out2 = nullptr, int split_col = 0) {
   // [buffer][hi / lo][chunk][row (+1 pad row per chunk: staggers the banks of the staging stores)][16 bf16]
   __shared__ __attribute__((aligned(16))) uint32_t As[2][2][kStepChunks][BM + 1][8];
 
@@ -275,7 +276,12 @@ linear_packed(const float* __restrict__ x, const float* __restrict__ x2, const u
     img0 = m0 / hm_rows;                              // uniform: once per workgroup
     first_sr = (int)(m0 - img0 * hm_rows);
   }
-  float* const out_tile = hm_rows == 0 ? out + m0 * N : out + img0 * (long long)(N / 32) * hm_rows * 32;
+  // split_col > 0: columns [0, split_col) go to `out` (row pitch split_col), the rest to `out2` (row pitch N - split_col):
+  // two Linear layers on the same input as one product.  A column block never straddles the split (host-checked).
+  const bool second = split_col > 0 && n0 >= split_col;     // workgroup-uniform
+  const int ld = split_col > 0 ? (second ? N - split_col : split_col) : N;   // row pitch = columns of this output
+  const int ncol0 = second ? split_col : 0;
+  float* const out_tile = hm_rows == 0 ? (second ? out2 : out) + m0 * ld : out + img0 * (long long)(N / 32) * hm_rows * 32;
 #pragma unroll
   for (int i = 0; i < TI; ++i) {
     uint32_t zero_rows = 0;                            // bit v: row of register v is masked
@@ -302,8 +308,8 @@ linear_packed(const float* __restrict__ x, const float* __restrict__ x2, const u
         const bool n_ok = FULL || n < N;
         const float bv = (bias && n_ok) ? bias[n] : 0.f;
         // element offset of (row, column n) inside the tile's output: row-major, or head-major with the image switch
-        const uint32_t col_off = hm_rows == 0 ? (uint32_t)n : (uint32_t)(n >> 5) * (uint32_t)hm_rows * 32u + (uint32_t)(n & 31);
-        uint32_t base_off = hm_rows == 0 ? lane_row * (uint32_t)N + col_off : col_off;
+        const uint32_t col_off = hm_rows == 0 ? (uint32_t)(n - ncol0) : (uint32_t)(n >> 5) * (uint32_t)hm_rows * 32u + (uint32_t)(n & 31);
+        uint32_t base_off = hm_rows == 0 ? lane_row * (uint32_t)ld + col_off : col_off;
         asm volatile("" : "+v"(base_off));   // opaque: `base_off + scalar` per element stays an add (see conv3x3.hip)
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
@@ -316,7 +322,7 @@ linear_packed(const float* __restrict__ x, const float* __restrict__ x2, const u
             if (act == 1) r = fmaxf(r, 0.f);
             uint32_t off;
             if (hm_rows == 0) {
-              off = base_off + (uint32_t)dr * (uint32_t)N;
+              off = base_off + (uint32_t)dr * (uint32_t)ld;
             } else {
               int sr = first_sr + rt;                     // row inside image img0, or past its end: the next image
               uint32_t img_off = 0;
@@ -592,7 +598,10 @@ int linear_hip_pack_weight_f32(const float* weight, int out_features, int in_fea
 }
 
 static int linear_impl(const float* x, const float* x2, const void* packed, const float* bias, const uint8_t* row_mask,
-                       long long rows, int in_features, int out_features, int hm_rows, int act, float* out, void* stream) {
+                       long long rows, int in_features, int out_features, int hm_rows, int act, float* out, void* stream,
+                       float* out2 = nullptr, int split_col = 0) {
+  if (split_col != 0 && (split_col < 0 || split_col >= out_features || split_col % 128 != 0 || hm_rows != 0 || !out2))
+    return dynmask_set_error(LINEAR_ERR_BAD_DIMS, "linear (two outputs): the split column must be a multiple of 128 inside (0, out_features)");
   if (act != 0 && act != 1) return dynmask_set_error(LINEAR_ERR_BAD_DIMS, "linear: activation must be 0 (none) or 1 (relu)");
   if (rows < 0 || in_features <= 0 || out_features <= 0)
     return dynmask_set_error(LINEAR_ERR_BAD_DIMS, "linear: bad dimensions");
@@ -611,29 +620,29 @@ static int linear_impl(const float* x, const float* x2, const void* packed, cons
   hipStream_t st = (hipStream_t)stream;
   static const int forced_tj = std::getenv("LINEAR_TJ") ? std::atoi(std::getenv("LINEAR_TJ")) : 0;   // A/B hook: 1, 2, 4
   // (the packed weights are padded to 128 columns only: a 256-column workgroup needs out_features % 256 == 0)
-  const bool wide_ok = out_features % 256 == 0 && mt * (out_features / 256) >= 512;
+  const bool wide_ok = out_features % 256 == 0 && mt * (out_features / 256) >= 512 && split_col % 256 == 0;
   if (wide_ok && (forced_tj == 4 || (forced_tj == 0 && out_features == 256))) {
     // 256 columns per workgroup: with out_features == 256 the activation tile is read, split and staged ONCE
     // (-3.5 % at K = 256, -7 % at K = 1024; no gain for wider outputs, profiles/r01_linear_tiles.txt)
     dim3 grid((unsigned)mt, (unsigned)((out_features + 255) / 256));
     if (x2) hipLaunchKernelGGL((linear::linear_packed<4, BM, true, 1>), grid, dim3(linear::kThreads), 0, st, x, x2, pk, bias, row_mask, rows,
-                       in_features, out_features, n_pad, hm_rows, act, out);
+                       in_features, out_features, n_pad, hm_rows, act, out, linear::LnArgs{nullptr, nullptr, nullptr, 0.f}, out2, split_col);
     else hipLaunchKernelGGL((linear::linear_packed<4, BM, false, 1>), grid, dim3(linear::kThreads), 0, st, x, x2, pk, bias, row_mask, rows,
-                       in_features, out_features, n_pad, hm_rows, act, out);
+                       in_features, out_features, n_pad, hm_rows, act, out, linear::LnArgs{nullptr, nullptr, nullptr, 0.f}, out2, split_col);
   } else
   // 128 columns per workgroup unless that leaves CUs idle
   if (forced_tj == 2 || (forced_tj == 0 && out_features > 64 && mt * ((out_features + 127) / 128) >= 512)) {
     dim3 grid((unsigned)mt, (unsigned)((out_features + 127) / 128));
     if (x2) hipLaunchKernelGGL((linear::linear_packed<2, BM, true, 1>), grid, dim3(linear::kThreads), 0, st, x, x2, pk, bias, row_mask, rows,
-                       in_features, out_features, n_pad, hm_rows, act, out);
+                       in_features, out_features, n_pad, hm_rows, act, out, linear::LnArgs{nullptr, nullptr, nullptr, 0.f}, out2, split_col);
     else hipLaunchKernelGGL((linear::linear_packed<2, BM, false, 1>), grid, dim3(linear::kThreads), 0, st, x, x2, pk, bias, row_mask, rows,
-                       in_features, out_features, n_pad, hm_rows, act, out);
+                       in_features, out_features, n_pad, hm_rows, act, out, linear::LnArgs{nullptr, nullptr, nullptr, 0.f}, out2, split_col);
   } else {
     dim3 grid((unsigned)mt, (unsigned)((out_features + 63) / 64));
     if (x2) hipLaunchKernelGGL((linear::linear_packed<1, BM, true, 2>), grid, dim3(linear::kThreads), 0, st, x, x2, pk, bias, row_mask, rows,
-                       in_features, out_features, n_pad, hm_rows, act, out);
+                       in_features, out_features, n_pad, hm_rows, act, out, linear::LnArgs{nullptr, nullptr, nullptr, 0.f}, out2, split_col);
     else hipLaunchKernelGGL((linear::linear_packed<1, BM, false, 2>), grid, dim3(linear::kThreads), 0, st, x, x2, pk, bias, row_mask, rows,
-                       in_features, out_features, n_pad, hm_rows, act, out);
+                       in_features, out_features, n_pad, hm_rows, act, out, linear::LnArgs{nullptr, nullptr, nullptr, 0.f}, out2, split_col);
   }
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : dynmask_set_error((int)e, hipGetErrorString(e));
@@ -678,6 +687,12 @@ int linear_hip_packed_ex_f32(const float* x, const float* x_add, const void* pac
                              const uint8_t* row_mask, long long rows, int in_features, int out_features, int activation,
                              float* out, void* stream) {
   return linear_impl(x, x_add, packed, bias, row_mask, rows, in_features, out_features, 0, activation, out, stream);
+}
+
+int linear_hip_packed_split_f32(const float* x, const float* x_add, const void* packed, const float* bias, long long rows,
+                                int in_features, int out_features, int split_col, float* out_a, float* out_b, void* stream) {
+  if (split_col <= 0) return dynmask_set_error(LINEAR_ERR_BAD_DIMS, "linear (two outputs): split_col must be > 0");
+  return linear_impl(x, x_add, packed, bias, nullptr, rows, in_features, out_features, 0, 0, out_a, stream, out_b, split_col);
 }
 
 int linear_hip_packed_ffn_f32(const float* x, const void* packed1, const float* bias1, const void* packed2,

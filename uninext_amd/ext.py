@@ -443,6 +443,39 @@ def linear_pack_weight(weight):
     return packed
 
 
+def linear_packed_split_forward(x, packed, split_col, out_features, bias=None, x_add=None):
+    """Two Linear layers on the same input as one product (include/linear_hip.h: linear_hip_packed_split_f32): `packed`
+    belongs to the row-wise concatenation [W_a; W_b] ([out_features, in_features]), `bias` to the concatenated biases;
+    returns (x' W_a^T + b_a  [..., split_col],  x' W_b^T + b_b  [..., out_features - split_col]) with x' = x + x_add."""
+    lib = _lib.load()
+    _check("x", x, x.device)
+    _check("packed", packed, x.device)
+    if x.dtype != torch.float32 or x.dim() < 1:
+        raise RuntimeError("linear_packed_split_forward: expected a float32 x [..., in_features]")
+    k, n, sc = x.shape[-1], int(out_features), int(split_col)
+    rows = x.numel() // k if k else 0
+    if bias is not None:
+        _check("bias", bias, x.device)
+        if bias.dtype != torch.float32 or bias.shape != (n,):
+            raise RuntimeError("linear_packed_split_forward: bias must be float32 [out_features]")
+    if x_add is not None:
+        _check("x_add", x_add, x.device)
+        if x_add.dtype != torch.float32 or x_add.shape != x.shape:
+            raise RuntimeError("linear_packed_split_forward: x_add must be float32 with the shape of x")
+    if packed.dtype != torch.uint8 or packed.numel() == 0 or packed.numel() != lib.linear_hip_packed_weight_bytes(n, k):
+        raise RuntimeError("linear_packed_split_forward: `packed` does not belong to a [%d, %d] weight" % (n, k))
+    out_a = torch.empty(x.shape[:-1] + (sc,), dtype=torch.float32, device=x.device)
+    out_b = torch.empty(x.shape[:-1] + (n - sc,), dtype=torch.float32, device=x.device)
+    if rows:
+        rc = lib.linear_hip_packed_split_f32(x.data_ptr(), x_add.data_ptr() if x_add is not None else None, packed.data_ptr(),
+                                             bias.data_ptr() if bias is not None else None, rows, k, n, sc,
+                                             out_a.data_ptr(), out_b.data_ptr(),
+                                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise RuntimeError("linear_hip_packed_split_f32: " + _lib.last_error())
+    return out_a, out_b
+
+
 def linear_packed_forward(x, packed, out_features, bias=None, row_mask=None, head_major_rows=0, x_add=None, relu=False):
     """`F.linear(x, W, bias)` with split-bf16 products (~2e-5 of the output scale) from weights prepared by
     linear_pack_weight; rows whose `row_mask` entry is True are written as zeros (the masked_fill of

@@ -25,7 +25,7 @@ from torch import nn
 from torch.nn.init import constant_, xavier_uniform_
 
 from .. import ext as MSDA
-from .._cache import CachedModuleMixin, CheckedOnce, packed_weight
+from .._cache import CachedModuleMixin, CheckedOnce, packed_weight, packed_weight_pair
 from ..functions import MSDeformAttnFunction
 
 
@@ -121,6 +121,19 @@ class MSDeformAttn(CachedModuleMixin, nn.Module):
                                    x, norm.weight, norm.bias, norm.eps)
         return None
 
+    def _project_offsets_and_logits(self, query, query_pos):
+        """sampling_offsets(query) and attention_weights(query) (ops/modules/ms_deform_attn.py:99-100).  Inference on the
+        GPU: ONE product with the concatenated weights and two outputs (linear_hip_packed_split_f32) -- the query, and the
+        positional embedding added to it, are read once instead of twice; every element is the same sum of products."""
+        so, aw = self.sampling_offsets, self.attention_weights
+        n_off = so.weight.shape[0]
+        if (self._fast_ok(so, query) and self._fast_ok(aw, query) and n_off % 128 == 0
+                and (query_pos is None or (query_pos.is_contiguous() and query_pos.shape == query.shape
+                                           and query_pos.dtype == query.dtype and not query_pos.requires_grad))):
+            packed, bias = packed_weight_pair(self, so, aw, MSDA.linear_pack_weight)
+            return MSDA.linear_packed_split_forward(query, packed, n_off, n_off + aw.weight.shape[0], bias, query_pos)
+        return self._project(so, query, x_add=query_pos), self._project(aw, query, x_add=query_pos)
+
     def _project(self, lin, x, row_mask=None, head_major_rows=0, x_add=None, relu=False):
         """`lin(x)` (then zero the rows where row_mask is True).  Inference on the GPU: include/linear_hip.h from a
         packed copy of the weight cached on the Linear and rebuilt when the parameter changes; head_major_rows = S
@@ -195,8 +208,7 @@ class MSDeformAttn(CachedModuleMixin, nn.Module):
         value = self._project(self.value_proj, input_flatten, input_padding_mask, Len_in if head_major else 0)
         if not head_major:
             value = value.view(N, Len_in, self.n_heads, head_dim)
-        offsets = self._project(self.sampling_offsets, query, x_add=query_pos)        # (N, Lq, M*L*P*2)
-        logits = self._project(self.attention_weights, query, x_add=query_pos)        # (N, Lq, M*L*P)
+        offsets, logits = self._project_offsets_and_logits(query, query_pos)          # (N, Lq, M*L*P*2), (N, Lq, M*L*P)
 
         if head_major:
             sampled = MSDA.ms_deform_attn_forward_fused(value, input_spatial_shapes, input_level_start_index,
