@@ -99,7 +99,7 @@ inline int ensure_dynamic_lds(const void* kernel, int bytes, std::atomic<uint64_
 
 // Variant numbering shared with include/msda_hip.h.
 enum Variant { kAuto = 0, kGeneric = 1, kLaneGroup = 2, kTiled = 3, kTiledL0 = 4, kTiledL0Big = 5, kLaneGroupCL = 6,
-               kLaneGroupL3 = 7, kLaneGroupP = 8, kWin = 9, kNumVariants = 10 };
+               kLaneGroupL3 = 7, kLaneGroupP = 8, kWin = 9, kWin2 = 10, kNumVariants = 11 };
 
 // msda_fwd.hip: forward with the MSDeformAttn prologue (softmax + sampling locations) fused in.
 bool fused_forward_ok(const Dims& d, int ref_dim);
@@ -123,6 +123,11 @@ int launch_forward_win_fused(const float* value, int head_major, const int64_t* 
 int forward_locality(double* far_fraction);      // reports so far (0: none yet) and the last one's far fraction
 int launch_forward_win(const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc, const float* attn,
                        const Dims& d, float* out, hipStream_t stream);
+
+// msda_fwd_win2.hip: the one-pass, 11-wave generation of the window kernel (same preconditions).
+bool win2_forward_ok(const Dims& d);
+int launch_forward_win2(const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc, const float* attn,
+                        const Dims& d, float* out, hipStream_t stream);
 
 // msda_fwd_tiled.hip: LDS-tiled encoder forward (fp32, D = 32, Lq == S).
 bool tiled_forward_ok(const Dims& d);

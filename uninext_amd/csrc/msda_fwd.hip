@@ -946,6 +946,11 @@ int launch_forward<float>(int variant, const float* value, const int64_t* shapes
   // ... and the LDS-window kernel beats msda_fwd_lg3 on the encoder shape while the samples stay near their queries:
   // win_forward_auto follows the locality the window kernel itself reported for the latest launches
   if (variant == kAuto) variant = win_forward_auto(d, stream) ? kWin : (lg3_ok(d) ? kLaneGroupL3 : (lg ? kLaneGroup : kGeneric));
+  if (variant == kWin2 && !win2_forward_ok(d)) variant = lg3_ok(d) ? kLaneGroupL3 : kLaneGroup;
+  if (variant == kWin2) {
+    *kernel_name = "msda_fwd_win2";
+    return launch_forward_win2(value, shapes, lsi, loc, attn, d, out, stream);
+  }
   if (variant == kWin && !win_forward_ok(d)) variant = lg3_ok(d) ? kLaneGroupL3 : kLaneGroup;
   if (variant == kWin) {
     *kernel_name = "msda_fwd_win";
