@@ -52,7 +52,14 @@ constexpr int kZeroBytes = kWW[0] * 128 + 256;                  // a bottom-row 
 struct Meta {
   int sum[4][4];                                                // per level: sum dx, sum dy, count, - (placement)
   int lvl[4][4];                                                // per level: H, W, first pixel, - (far path: level picked per quad)
+  int next[4];                                                  // persistent grid: the workgroup's next item
 };
+// Persistent grid (launch_forward_win2): K workgroups per head walk the head's items; after its first item (= its index) a
+// workgroup draws the next one from a per-head ticket counter, so that nobody idles while a neighbour still has a fifth
+// item.  One counter set per launch (ring of kTicketSets, the host passes the index): launches on different streams do not
+// share counters; the last workgroup of a head to finish puts the head's two words back to zero.
+constexpr int kTicketSets = 32, kTicketHeads = 64, kPersistDefault = 1 << 30;
+__device__ unsigned g_win2_tickets[kTicketSets][kTicketHeads][2];   // [set][head]: tickets drawn, workgroups done
 constexpr int kMetaOff = kZeroOff + kZeroBytes;
 constexpr int kLdsBytes = kMetaOff + ((sizeof(Meta) + 15) / 16) * 16;
 static_assert(kLdsBytes <= 80 * 1024, "two workgroups per CU");
@@ -169,7 +176,7 @@ struct Smp {      // one prepared NEAR sample (dead and far samples: zero weight
 #endif
 __global__ void __launch_bounds__(kT, MSDA_WIN2_WAVES_PER_EU)
 msda_fwd_win2(const float* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
-              const float* __restrict__ loc, const float* __restrict__ attn, Dims d, float* __restrict__ out) {
+              const float* __restrict__ loc, const float* __restrict__ attn, Dims d, float* __restrict__ out, int ticket_set) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef MSDA_WIN2_PROF
   {
@@ -196,7 +203,17 @@ msda_fwd_win2(const float* __restrict__ value, const int64_t* __restrict__ shape
   }
   const int TY = (lvH[0] + kTH - 1) / kTH, TX = (lvW[0] + kTW - 1) / kTW;
   const int ntiles = TY * TX, nitems = d.N * ntiles;       // work items of this head: (image, tile), image-major
-  if (kk >= nitems) return;                                // over-provisioned part of the grid
+  unsigned* const tickets = ticket_set >= 0 ? &g_win2_tickets[ticket_set][m][0] : nullptr;   // dynamic item distribution?
+  auto retire = [&]() __attribute__((always_inline)) {     // one call per workgroup: the head's last one resets the counters
+    if (tickets && tid == 0 && atomicAdd(&tickets[1], 1u) == (unsigned)K - 1u) {
+      tickets[0] = 0u;
+      tickets[1] = 0u;
+    }
+  };
+  if (kk >= nitems) {                                      // over-provisioned part of the grid
+    retire();
+    return;
+  }
 
   // the all-zero region, the placement sums, the level table of the far path (visible after the first barrier)
   if (tid < kZeroBytes / 16) *reinterpret_cast<f32x4*>(smem + kZeroOff + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -211,7 +228,7 @@ msda_fwd_win2(const float* __restrict__ value, const int64_t* __restrict__ shape
   const uint32_t pixB = (uint32_t)M * 128u;                // bytes from a pixel of head m to the next one
   const uint32_t hoff = (uint32_t)m * 128u;
   W2_STOP(1);
-  for (int item = kk; item < nitems; item += K) {
+  for (int item = kk; item < nitems;) {
     // One item per workgroup at every shape this kernel is launched on in practice, so loop-invariant code motion has
     // nothing to gain here -- but it hoists dozens of per-level / per-wave values out of the loop and spills them at once
     // (the kernel lives at the 80-register limit of 6 waves per SIMD).  Everything the body derives values from passes
@@ -221,6 +238,8 @@ msda_fwd_win2(const float* __restrict__ value, const int64_t* __restrict__ shape
 #pragma unroll
     for (int l = 0; l < 4; ++l) asm volatile("" : "+s"(lvH[l]), "+s"(lvW[l]), "+s"(lvS[l]));
     W2_STAMP(0);
+    unsigned drawn = 0;
+    if (tickets && tid == 0) drawn = atomicAdd(&tickets[0], 1u);   // in flight until it is published below
     // quotients by v_rcp_f32: x + 0.5 is at least 0.5 / divisor away from an integer, far beyond the 1 ulp of the reciprocal
     const int b = to_sgpr((int)(((float)item + 0.5f) * __builtin_amdgcn_rcpf((float)ntiles_)));
     const int64_t pair_img = (int64_t)b * d.Lq * M + m;     // pair (query 0, head m) of this item's image: uniform bases, 32-bit per-lane offsets
@@ -529,6 +548,7 @@ msda_fwd_win2(const float* __restrict__ value, const int64_t* __restrict__ shape
         while (__ballot(fm != 0u)) far_step();
 #endif
         if (pass == 0) {
+          if (tickets && tid == 0) mt.next[0] = K + (int)drawn;
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of the windows has landed
           W2_STAMP(10);
           lds_barrier();                                       // #3 ... and everybody else's
@@ -693,7 +713,11 @@ msda_fwd_win2(const float* __restrict__ value, const int64_t* __restrict__ shape
       W2_STAMP(15);                                          // output stores acknowledged
 #endif
     }
+    // the next item: the ticket published before barrier #3 (nobody overwrites it before everybody is past the next
+    // item's barrier #1), or the static stride
+    item = tickets ? __builtin_amdgcn_readfirstlane(*(volatile int*)&mt.next[0]) : item + K;
   }
+  retire();
 }
 
 #ifdef MSDA_WIN2_PROF
@@ -721,13 +745,28 @@ int launch_forward_win2(const float* value, const int64_t* shapes, const int64_t
   // items kk, kk + K, ...  Head m = blockIdx.x, i.e. (by the observed round-robin placement of the linear workgroup id)
   // XCD m % 8 only ever touches head m's slice of `value` when M is a multiple of 8.
   int K = d.N * ((d.S + 127) / 128);
-  // MSDA_WIN2_PERSIST=n (A/B switch): n workgroups per head walk the items instead of one workgroup per item
-  static const int persist = std::getenv("MSDA_WIN2_PERSIST") ? std::atoi(std::getenv("MSDA_WIN2_PERSIST")) : 0;
-  if (persist > 0) K = persist;
+  // MSDA_WIN2_PERSIST=n (A/B switch; default below): n > 0: n workgroups per head walk the items, -n: the same with the
+  // static stride instead of tickets, 0: one workgroup per item
+  static const int persist_env = std::getenv("MSDA_WIN2_PERSIST") ? std::atoi(std::getenv("MSDA_WIN2_PERSIST")) : kPersistDefault;
+  int persist = persist_env;
+  if (persist == kPersistDefault) {                        // two resident workgroups per CU, spread over the heads
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    persist = (2 * cus + d.M - 1) / d.M;
+  }
+  static std::atomic<unsigned> launch_seq{0};
+  int ticket_set = -1;
+  if (persist != 0) {
+    const int want = persist > 0 ? persist : -persist;
+    if (want < K) {                                        // fewer items than that: one workgroup per item is the same thing
+      K = want;
+      if (persist > 0 && d.M <= kTicketHeads) ticket_set = (int)(launch_seq.fetch_add(1, std::memory_order_relaxed) % kTicketSets);
+    }
+  }
   if (K < 1) K = 1;
   if (K > 65535) K = 65535;
   hipLaunchKernelGGL(msda_fwd_win2, dim3((unsigned)d.M, (unsigned)K), dim3(kT), kLdsBytes, stream, value, shapes, lsi, loc,
-                     attn, d, out);
+                     attn, d, out, ticket_set);
   return (int)hipGetLastError();
 }
 
