@@ -28,8 +28,10 @@ Extra objects on the JSON line (all measured in this run, after the timed region
                 (ops/test.py:34, no locality) and `wide` (model-like with sigma = 6 px offsets).
   forward_kernels  both encoder-forward kernels pinned (msda_fwd_win: LDS windows; msda_fwd_lg3: gather), launch time
                 on the three flavours, and the far fraction the window kernel reports for each.  The timed region
-                runs variant 0, which follows that report (include/msda_hip.h: window kernel while <= 0.20).
-  backward      BASELINE configs[4] (training step): the encoder-call and the decoder-call backward launches
+                runs variant 0, which follows that report PER CALL SITE (include/msda_hip.h: window kernel while
+                <= 0.20; the six encoder layers are six call sites).
+  backward      BASELINE configs[4] (training step) at the TRAINING shapes (800x1344: S = 22323, decoder Lq = 1100): the
+                encoder-call and the decoder-call backward launches
                 (grad_value pre-zeroed outside the events): kernel, launch_us, algorithmic bytes
                 (N*(2048*S + 4096*Lq)), achieved GB/s, fraction of 8 TB/s, traffic (as above, or null).
   train_step    12 forward + 12 backward calls through MSDeformAttnFunction (autograd), bs 2: ms per step.
@@ -115,6 +117,15 @@ def flavour_kwargs(flavour):
     return dict(flavour=flavour)
 
 
+def build_train_inputs(flavour, rank, device="cuda"):
+    """BASELINE configs[4] per-GPU share at the TRAINING shapes: bs 2 padded to 800 x 1344 (S = 22323), decoder with the 1100
+    queries of the DN decoder (uninext_amd.workloads: r50_train_encoder / r50_train_decoder)."""
+    fl = "wide" if flavour == "wide" else flavour
+    enc = [workloads.make_workload("r50_train_encoder", fl, seed=100 * rank + 20 + i, device=device) for i in range(3)]
+    dec = [workloads.make_workload("r50_train_decoder", fl, seed=100 * rank + 60 + i, device=device) for i in range(3)]
+    return enc, dec
+
+
 def build_inputs(flavour, rank, device="cuda"):
     kw = flavour_kwargs(flavour)
     enc = [workloads.make_inputs("encoder", batch=BATCH, seed=100 * rank + i, device=device, **kw) for i in range(ENC_LAYERS)]
@@ -122,15 +133,17 @@ def build_inputs(flavour, rank, device="cuda"):
     return enc, dec
 
 
-def call(x):
-    return MSDA.ms_deform_attn_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], 64)
+def call(x, site=0):
+    """One operator call from call site `site` (include/msda_hip.h: the library picks its encoder-forward kernel per site)."""
+    with MSDA.call_site(site):
+        return MSDA.ms_deform_attn_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], 64)
 
 
 def run_step(enc, dec, ev=None):
     if ev is not None:
         ev[0].record()
-    for x in enc:
-        call(x)
+    for i, x in enumerate(enc):     # six encoder layers = six call sites, as in the model (MSDeformAttn modules pass their own)
+        call(x, 1 + i)
     if ev is not None:
         ev[1].record()
     for x in dec:
@@ -183,16 +196,16 @@ def time_events(fn, reps, pre=None):
 
 def measure_flavours(rank, reps=12):
     out = {}
-    for fl in ("uniform", "wide"):
+    for idx, fl in enumerate(("uniform", "wide")):
+        site = 10 + idx                   # a call site of its own: the choice settles at the site's third call
         xs = [workloads.make_inputs("encoder", batch=BATCH, seed=100 * rank + 70 + i, **flavour_kwargs(fl)) for i in range(3)]
-        for x in xs:
-            call(x)
-            torch.cuda.synchronize()      # variant 0 follows the locality report of the previous launch: let it land
+        for x in xs + xs[:1]:
+            call(x, site)
         k = [0]
 
         def one():
             k[0] += 1
-            call(xs[k[0] % len(xs)])
+            call(xs[k[0] % len(xs)], site)
         out[fl] = {"launch_us": time_events(one, reps), "kernel": _lib.last_kernel("forward")}
         del xs
     return out
@@ -207,7 +220,11 @@ def measure_forward_kernels(enc, reps=12):
     alg = workloads.algorithmic_bytes_forward(BATCH, S, S)
     sets = {"model": enc[:3]}
     for fl in ("uniform", "wide"):
-        sets[fl] = [workloads.make_inputs("encoder", batch=BATCH, seed=70 + i, **flavour_kwargs(fl)) for i in range(2)]
+        sets[fl] = [workloads.make_inputs("encoder", batch=BATCH, seed=70 + i, **flavour_kwargs(fl)) for i in range(3)]   # rotating: ~0.5 GB, past the 256 MB Infinity Cache
+    for idx, (fl, xs) in enumerate(sets.items()):      # far fractions: two reporting calls of variant 0 on a fresh call site each
+        for x in xs[:2]:
+            call(x, 20 + idx)
+        out.setdefault("far_fraction", {})[fl] = _lib.forward_locality()[1]
     try:
         for name in ("msda_fwd_win", "msda_fwd_lg3"):
             _lib.set_variant("forward", name)
@@ -220,19 +237,14 @@ def measure_forward_kernels(enc, reps=12):
                 def one():
                     k[0] += 1
                     call(xs[k[0] % len(xs)])
-                us = time_events(one, reps if fl == "model" else 6)
+                us = time_events(one, reps if fl == "model" else 9)
                 rec[fl + "_launch_us"] = us
-                if name == "msda_fwd_win":
-                    torch.cuda.synchronize()
-                    out.setdefault("far_fraction", {})[fl] = _lib.forward_locality()[1]
             rec["achieved"] = alg / rec["model_launch_us"] / 1e3
             rec["frac"] = rec["achieved"] / HBM_PEAK_GBS
             rec["traffic"] = committed_traffic(name, "forward_encoder") or committed_traffic(name, "forward_encoder_lg3")
             out[name] = rec
     finally:
         _lib.set_variant("forward", "auto")
-        call(enc[0])                      # leave the locality report on the headline flavour
-        torch.cuda.synchronize()
     return out
 
 
@@ -277,6 +289,7 @@ def measure_backward(enc, dec, reps=10):
         ach = alg / us / 1e3
         out[kind] = {"kernel": kern, "launch_us": us, "algorithmic_bytes": alg, "achieved": ach, "unit": "GB/s",
                      "frac": ach / HBM_PEAK_GBS, "traffic": committed_traffic(kern, "backward_" + kind),
+                     "shape": "N=%d S=%d Lq=%d" % (N, S, Lq),
                      "note": "launch only; the grad_value memset (N*S*1024 B) is outside the events"}
         del sets
     return out
@@ -314,8 +327,9 @@ def measure_train_step(enc, dec, world, reps=5):
     barrier(world)
     dt = max_over_ranks(time.perf_counter() - t0, world) / reps
     return {"ms_per_step": 1e3 * dt, "frames_per_s": world * BATCH / dt,
-            "workload": "BASELINE configs[4] per-GPU share: bs 2, 6 encoder + 6 decoder MSDeformAttn forward AND "
-                        "backward calls through MSDeformAttnFunction (autograd, incl. output allocation + memsets)",
+            "workload": "BASELINE configs[4] per-GPU share at the training shapes (bs 2, 800x1344: S=%d; decoder Lq=%d): "
+                        "6 encoder + 6 decoder MSDeformAttn forward AND backward calls through MSDeformAttnFunction "
+                        "(autograd, incl. output allocation + memsets)" % (enc[0]["value"].shape[1], dec[0]["loc"].shape[1]),
             "kernels": {"forward": _lib.last_kernel("forward"), "backward_last": _lib.last_kernel("backward")}}
 
 
@@ -413,10 +427,13 @@ def main():
     enc, dec = build_inputs(args.flavour, rank)
     S = enc[0]["value"].shape[1]
 
-    call(enc[0])
-    enc_kernel = _lib.last_kernel("forward")   # the kernel the encoder launches take (decoder calls may differ)
+    for _ in range(3):                          # set-up, not warm-up steps: a call site's kernel choice settles at its third call
+        for i, x in enumerate(enc):
+            call(x, 1 + i)
     for _ in range(max(args.warmup, 0)):
         run_step(enc, dec)
+    call(enc[0], 1)
+    enc_kernel = _lib.last_kernel("forward")   # the kernel the encoder launches take (decoder calls may differ)
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     barrier(world)
@@ -445,12 +462,16 @@ def main():
             extra("flavours", lambda: measure_flavours(rank))
             if args.flavour == "model":
                 extra("forward_kernels", lambda: measure_forward_kernels(enc))
+        if want & {"backward", "train", "ddp"}:
+            # config 5's legs run on the TRAINING shapes (three input sets per call kind; a layer index i takes set i % 3)
+            tenc, tdec = build_train_inputs(args.flavour, rank)
+            tenc6, tdec6 = [tenc[i % 3] for i in range(ENC_LAYERS)], [tdec[i % 3] for i in range(DEC_LAYERS)]
         if "backward" in want:
-            extra("backward", lambda: measure_backward(enc, dec))
+            extra("backward", lambda: measure_backward(tenc, tdec))
         if "train" in want:
-            extra("train_step", lambda: measure_train_step(enc, dec, world))
+            extra("train_step", lambda: measure_train_step(tenc6, tdec6, world))
         if "ddp" in want and world > 1:
-            extra("ddp", lambda: measure_ddp(enc, dec, world))
+            extra("ddp", lambda: measure_ddp(tenc6, tdec6, world))
 
     if rank == 0:
         enc_ms = sum(a.elapsed_time(b) for a, b in events) / (args.steps * ENC_LAYERS)  # per encoder launch

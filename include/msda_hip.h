@@ -180,19 +180,37 @@ const char* msda_hip_last_kernel(int which);
 
 /*
  * Automatic choice of the fp32 forward kernel on the encoder shape (num_query == spatial_size, channels 32, 4 levels
- * x 4 points): the LDS-window kernel (msda_fwd_win) is faster than the gather kernel (msda_fwd_lg3) while the samples
- * of a query stay within a few pixels of it and slower when they do not, and only the sampling locations tell.  Every
- * launch of the window kernel counts the samples that missed their tile's windows and its last workgroup stores the
- * count in host-mapped memory; variant 0 (automatic) follows the latest report -- window kernel while the far
- * fraction is <= 0.20 -- and, while it runs the gather kernel, sends every 64th call through the window kernel to
- * refresh the report.  The choice never changes a result beyond fp32 summation order.  MSDA_HIP_FWD_ADAPTIVE=0 in
- * the environment pins variant 0 to the gather kernel.
+ * x 4 points).  The LDS-window kernel (msda_fwd_win) is faster than the gather kernel (msda_fwd_lg3) while the samples
+ * of a query stay within a few pixels of it and slower when they do not, and only the sampling locations tell.
  *
- * The fused entry points (msda_hip_forward_fused[_hm]_f32) choose between the same two kernels in the same way.
+ * msda_hip_set_call_context(call_site, flags) describes the NEXT forward call made from the calling thread (operator or
+ * fused entry point; the context is consumed by that call):
+ *   call_site   0..63: the caller's slot.  The choice is made PER CALL SITE -- the six encoder layers of a model each
+ *               pass their own and each converge on their own kernel.  < 0: no automatic choice (gather kernel).
+ *   flags       MSDA_CTX_GEOMETRY_CHECKED  the caller vouches that sum_l H_l * W_l == spatial_size and that
+ *                                          level_start_index holds the prefix sums of H_l * W_l.  PRECONDITION of the
+ *                                          window kernels (they enumerate the queries from the level shapes); without it
+ *                                          variant 0 takes the gather kernel, which walks 0..num_query-1 for any shapes.
+ *                                          (Pinned window variants 9 / 10 assume it; they never read or write outside
+ *                                          the tensors, but rows >= sum H_l * W_l would be left unwritten.)
+ *               MSDA_CTX_DETERMINISTIC     pin the gather kernel (one kernel, no history).
+ * Without a context variant 0 takes the gather kernel: a plain msda_hip_forward_f32 call is history-free.
  *
- * msda_hip_forward_locality: number of reports received so far on the current device (0: none yet; the report of a
- * launch lands when that launch completes) and, in *far_fraction (may be NULL), the far fraction of the latest one.
+ * With a context: every reporting launch of the window kernel counts the samples that missed their tile's windows into
+ * a counter of its own and its last workgroup stores (count, sequence number) in host-mapped memory.  The report of a
+ * launch is consumed at the call site's SECOND call after it, behind a wait on an event recorded after that launch
+ * (normally complete long before), so the kernel a call takes depends on the call sequence only, never on timing: window
+ * kernel (every 8th launch reporting once the first reports are in) until a report says far fraction > 0.20, then the
+ * gather kernel with every 64th call sent through the window kernel to refresh the report.  Two runs of the same call sequence are bitwise equal; the two kernels differ from each
+ * other in fp32 summation order only.  Under a stream capture (events cannot be waited for) and with
+ * MSDA_HIP_FWD_ADAPTIVE=0 in the environment variant 0 takes the gather kernel.
+ *
+ * msda_hip_forward_locality: number of reports consumed so far on the call site used last on the current device (it
+ * waits for the launches made so far on that site) and, in *far_fraction (may be NULL), the far fraction of the latest.
  */
+#define MSDA_CTX_GEOMETRY_CHECKED 1u
+#define MSDA_CTX_DETERMINISTIC 2u
+void msda_hip_set_call_context(int call_site, unsigned flags);
 int msda_hip_forward_locality(double* far_fraction);
 
 #ifdef __cplusplus

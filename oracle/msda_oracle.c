@@ -31,6 +31,17 @@
 #include <stdint.h>
 #include <string.h>
 
+/*
+ * Pixel coordinate of a sample: loc * size - 0.5 as ONE fused multiply-add.  The reference's CUDA source writes
+ * `loc_h * spatial_h - 0.5` (cuh:285-286), which nvcc contracts into an FMA (default -fmad=true); floor() of the result
+ * decides the bilinear cell, so for a sample within an ulp of a cell edge one rounding or two pick different -- equally
+ * valid -- one-sided derivatives (about one sample in a million; found on the RefCOCO-size pyramids).  The restatement
+ * follows the compiled reference.  float: the double product of two floats is exact and so is the sum, one rounding to
+ * float at the end; double: fma() is exact by definition.
+ */
+static inline float msda_coord_f32(float loc, int size) { return (float)((double)loc * (double)size - 0.5); }
+static inline double msda_coord_f64(double loc, int size) { return fma(loc, (double)size, -0.5); }
+
 #define MSDA_ORACLE_DEFINE(T, SUFFIX)                                                     \
                                                                                           \
   int msda_oracle_forward_##SUFFIX(const T* value, const int64_t* shapes,                 \
@@ -53,8 +64,8 @@
               const T loc_w = l_ptr[(l * P + p) * 2];                                     \
               const T loc_h = l_ptr[(l * P + p) * 2 + 1];                                 \
               const T weight = a_ptr[l * P + p];                                          \
-              const T h_im = loc_h * H - (T)0.5;                                          \
-              const T w_im = loc_w * W - (T)0.5;                                          \
+              const T h_im = msda_coord_##SUFFIX(loc_h, H);                               \
+              const T w_im = msda_coord_##SUFFIX(loc_w, W);                               \
               if (!(h_im > -1 && w_im > -1 && h_im < H && w_im < W)) continue;            \
               const int h_low = (int)floor(h_im), w_low = (int)floor(w_im);               \
               const int h_high = h_low + 1, w_high = w_low + 1;                           \
@@ -103,8 +114,8 @@
               const int s = l * P + p;                                                    \
               const T loc_w = l_ptr[s * 2], loc_h = l_ptr[s * 2 + 1];                     \
               const T weight = a_ptr[s];                                                  \
-              const T h_im = loc_h * H - (T)0.5;                                          \
-              const T w_im = loc_w * W - (T)0.5;                                          \
+              const T h_im = msda_coord_##SUFFIX(loc_h, H);                               \
+              const T w_im = msda_coord_##SUFFIX(loc_w, W);                               \
               if (!(h_im > -1 && w_im > -1 && h_im < H && w_im < W)) continue;            \
               const int h_low = (int)floor(h_im), w_low = (int)floor(w_im);               \
               const int h_high = h_low + 1, w_high = w_low + 1;                           \

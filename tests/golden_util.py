@@ -55,3 +55,15 @@ def scaled_err(a, b):
     b64 = np.asarray(b, dtype=np.float64)
     scale = max(1.0, float(np.max(np.abs(b64)))) if b64.size else 1.0
     return max_abs(a, b) / scale
+
+
+def grad_loc_err(gl, ref, shapes):
+    """Worst ratio of |grad_sampling_loc - ref| to its bound 1e-4 * max(W_l, H_l) over the levels: the derivative with
+    respect to a NORMALISED location is the pixel-space derivative times W_l (x) / H_l (y) (cuh:157-158), so its rounding
+    error carries that factor.  gl, ref: [N, Lq, M, L, P, 2]; shapes: [L, 2] (H, W).  < 1 passes."""
+    d = np.abs(np.asarray(gl, dtype=np.float64) - np.asarray(ref, dtype=np.float64))
+    worst = 0.0
+    for l, (h, w) in enumerate(np.asarray(shapes).tolist()):
+        if d[:, :, :, l].size:
+            worst = max(worst, float(d[:, :, :, l].max()) / (1e-4 * max(h, w)))
+    return worst

@@ -109,3 +109,21 @@ def test_workload_shapes_and_bytes():
     assert abs(w.algorithmic_bytes_forward(1, 22223, 900) / 1e6 - 25.06) < 0.01
     assert abs(w.algorithmic_bytes_backward(1, 22223, 22223) / 1e6 - 136.5) < 0.1
     assert abs(w.algorithmic_bytes_backward(1, 22223, 900) / 1e6 - 49.2) < 0.01
+
+
+def test_named_workloads_cover_the_baseline_configs():
+    """uninext_amd.workloads.WORKLOADS: one op-level shape set per BASELINE.json config that reaches the op (configs[1..4]); the
+    pyramids follow from the image sizes (ceil(size / stride), strides 8 / 16 / 32 / 64) and the level start indices from them."""
+    from uninext_amd import workloads
+    assert {w["config"] for w in workloads.WORKLOADS.values()} == {1, 2, 3, 4}
+    assert workloads.pyramid(800, 1344) == workloads.R50_LEVELS_TRAIN
+    assert workloads.WORKLOADS["r50_train_decoder"]["num_query"] == 1100        # 900 matching + 200 denoising queries
+    assert workloads.WORKLOADS["ytvis480_clip_encoder"]["batch"] == 5
+    for name, w in workloads.WORKLOADS.items():
+        x = workloads.make_workload(name, device="cpu") if w["batch"] * sum(h * ww for h, ww in w["levels"]) < 30000 else None
+        if x is None:
+            continue
+        S = sum(h * ww for h, ww in w["levels"])
+        assert x["value"].shape == (w["batch"], S, 8, 32)
+        assert x["loc"].shape[1] == (w["num_query"] or S)
+        assert int(x["lsi"][-1]) + w["levels"][-1][0] * w["levels"][-1][1] == S

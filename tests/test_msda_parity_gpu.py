@@ -69,7 +69,7 @@ def test_full_size_forward_every_query(flavour, dev, api):
     MSDA, lib = api
     x = _inputs(flavour, workloads.R50_LEVELS_INFER, 13, dev)
     ref = msda_oracle.forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
-    for variant in ("auto", "msda_fwd_lanegroup", "msda_fwd_win"):
+    for variant in ("auto", "msda_fwd_lanegroup", "msda_fwd_win", "msda_fwd_win2"):
         out = _fwd(MSDA, lib, x, variant)
         want = lib.last_kernel("forward")
         assert want in (("msda_fwd_lg3", "msda_fwd_win") if variant == "auto" else (variant,))
@@ -78,10 +78,11 @@ def test_full_size_forward_every_query(flavour, dev, api):
         assert err < 1e-4, (variant, err)
 
 
+@pytest.mark.parametrize("kernel", ["msda_fwd_win", "msda_fwd_win2"])
 @pytest.mark.parametrize("flavour", ["model", "uniform", "wide"])
 @pytest.mark.parametrize("levels", ODD_PYRAMIDS)
-def test_window_forward_on_odd_pyramids(levels, flavour, dev, api):
-    """msda_fwd_win: every query of odd pyramids; 'uniform' / 'wide' run (almost) everything through its far path,
+def test_window_forward_on_odd_pyramids(levels, flavour, kernel, dev, api):
+    """msda_fwd_win / msda_fwd_win2: every query of odd pyramids; 'uniform' / 'wide' run (almost) everything through its far path,
     'model' through the LDS windows.  Poisoned locations (NaN / inf / huge) must stay confined to their own sample."""
     from oracle import msda_oracle
     MSDA, lib = api
@@ -89,50 +90,115 @@ def test_window_forward_on_odd_pyramids(levels, flavour, dev, api):
     x["loc"][0, 3, 0, 0, 0, 0] = float("nan")
     x["loc"][0, 5, 7, 3, 3, 1] = float("inf")
     x["loc"][1, 17, 2, 1, 2, 0] = -1e30
-    out = _fwd(MSDA, lib, x, "msda_fwd_win")
-    assert lib.last_kernel("forward") == "msda_fwd_win"
-    again = _fwd(MSDA, lib, x, "msda_fwd_win")
+    out = _fwd(MSDA, lib, x, kernel)
+    assert lib.last_kernel("forward") == kernel
+    again = _fwd(MSDA, lib, x, kernel)
     assert torch.isfinite(out).all() and torch.equal(out, again)          # no atomics: bitwise repeatable
     ref = msda_oracle.forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
     assert float(np.abs(out.cpu().numpy().astype(np.float64) - ref).max()) < 1e-4
 
 
+def _auto(MSDA, lib, x, site):
+    from uninext_amd import ext
+    with ext.call_site(site):
+        out = _fwd(MSDA, lib, x, "auto")
+    return out, lib.last_kernel("forward")
+
+
 def test_automatic_forward_choice_follows_the_reported_locality(dev, api):
-    """include/msda_hip.h: a window-kernel launch reports the fraction of samples that missed its windows; variant 0
-    takes the window kernel while the latest report is <= 0.20 and the gather kernel otherwise, re-probing every
-    64th call.  The choice never changes a result beyond summation order."""
+    """include/msda_hip.h: a reporting window-kernel launch counts the samples that missed its windows; a call site takes
+    the window kernel until a report says far fraction > 0.20 and the gather kernel afterwards, re-probing every 64th call.
+    Reports are consumed at the site's second call after the launch: the kernel sequence is a function of the call
+    sequence.  The choice never changes a result beyond summation order."""
     from uninext_amd import workloads
     MSDA, lib = api
+    site = 40
     xm = _inputs("model", workloads.R50_LEVELS_INFER, 31, dev)
     xu = _inputs("uniform", workloads.R50_LEVELS_INFER, 32, dev)
-    n0, _ = lib.forward_locality()
-    ref_m = _fwd(MSDA, lib, xm, "msda_fwd_win")
-    torch.cuda.synchronize()
-    n1, far_m = lib.forward_locality()
-    assert n1 == n0 + 1 and 0.0 < far_m < 0.1, (n0, n1, far_m)
-    out = _fwd(MSDA, lib, xm, "auto")                      # near samples: the window kernel again
-    assert lib.last_kernel("forward") == "msda_fwd_win" and torch.equal(out, ref_m)
-    torch.cuda.synchronize()
-    _fwd(MSDA, lib, xu, "auto")                            # still following the last report; reports 0.9x itself
-    assert lib.last_kernel("forward") == "msda_fwd_win"
-    torch.cuda.synchronize()
-    n2, far_u = lib.forward_locality()
-    assert n2 == n1 + 2 and far_u > 0.8, (n2, far_u)
-    ref_u = _fwd(MSDA, lib, xu, "msda_fwd_lg3")
+    ref_m, ref_u = _fwd(MSDA, lib, xm, "msda_fwd_win"), _fwd(MSDA, lib, xu, "msda_fwd_lg3")
+    out, k = _auto(MSDA, lib, xm, site)                     # nothing known about this site: window kernel, reporting
+    assert k == "msda_fwd_win" and torch.equal(out, ref_m)
+    n, far_m = lib.forward_locality()
+    assert n >= 1 and 0.0 < far_m < 0.1, (n, far_m)
+    kernels = [_auto(MSDA, lib, xu, site)[1] for _ in range(4)]
+    # call 1 on far data still follows the report of the near data, as does call 2 (its own report is due at the second
+    # call after it); from call 3 on the site runs the gather kernel
+    assert kernels == ["msda_fwd_win", "msda_fwd_win", "msda_fwd_lg3", "msda_fwd_lg3"], kernels
+    _, far_u = lib.forward_locality()
+    assert far_u > 0.8, far_u
     kernels = []
     for _ in range(70):
-        out = _fwd(MSDA, lib, xu, "auto")
-        kernels.append(lib.last_kernel("forward"))
-        torch.cuda.synchronize()
-    assert kernels.count("msda_fwd_win") == 1 and kernels[63] == "msda_fwd_win", kernels    # the 64th call re-probes
-    assert torch.equal(out, ref_u)                          # ... and the others run the gather kernel
+        out, k = _auto(MSDA, lib, xu, site)
+        kernels.append(k)
+    assert kernels.count("msda_fwd_win") == 1, kernels                        # one re-probe in 64 calls ...
+    assert torch.equal(out, ref_u)                                             # ... the others run the gather kernel
     kernels = []
-    for _ in range(66):                                     # back to near samples: the next probe switches over
-        out = _fwd(MSDA, lib, xm, "auto")
-        kernels.append(lib.last_kernel("forward"))
-        torch.cuda.synchronize()
+    for _ in range(70):                                                        # back to near samples: the next probe switches over
+        out, k = _auto(MSDA, lib, xm, site)
+        kernels.append(k)
     assert kernels[-1] == "msda_fwd_win" and torch.equal(out, ref_m), kernels
     assert "msda_fwd_lg3" in kernels[:58]
+
+
+def test_forward_choice_is_per_call_site_and_repeatable(dev, api):
+    """VERDICT r02 item 4 / ADVICE: a local and a far-heavy tensor alternate call by call on two call sites; after warm-up
+    each site runs ITS faster kernel (one global state would have every call follow the other tensor's report), and the
+    same call sequence replayed on two fresh sites takes the same kernels and returns bitwise equal outputs."""
+    from uninext_amd import workloads
+    MSDA, lib = api
+    xm = _inputs("model", workloads.R50_LEVELS_INFER, 33, dev)
+    xu = _inputs("uniform", workloads.R50_LEVELS_INFER, 34, dev)
+
+    def run(site_m, site_u, n=8):
+        seq, outs = [], []
+        for _ in range(n):
+            om, km = _auto(MSDA, lib, xm, site_m)
+            ou, ku = _auto(MSDA, lib, xu, site_u)
+            seq.append((km, ku))
+            outs.append((om, ou))
+        return seq, outs
+    seq_a, outs_a = run(41, 42)
+    assert seq_a[-1] == ("msda_fwd_win", "msda_fwd_lg3") and seq_a[-2] == seq_a[-1], seq_a
+    seq_b, outs_b = run(43, 44)
+    assert seq_a == seq_b, (seq_a, seq_b)
+    for (am, au), (bm, bu) in zip(outs_a, outs_b):
+        assert torch.equal(am, bm) and torch.equal(au, bu)
+
+
+def test_forward_choice_is_pinned_without_context_or_when_determinism_is_asked_for(dev, api):
+    """A plain C-ABI call (no context), unverifiable geometry (sum H*W != spatial_size: legal for the reference operator,
+    not for the window kernels -- ADVICE r02) and torch.use_deterministic_algorithms(True) all take the gather kernel."""
+    import ctypes
+    from uninext_amd import ext, workloads
+    MSDA, lib = api
+    x = _inputs("model", workloads.R50_LEVELS_INFER, 35, dev)
+    N, S, M, D = x["value"].shape
+    out = torch.empty(N, S, M * D, device=dev)
+    rc = lib.load().msda_hip_forward_f32(x["value"].data_ptr(), x["shapes"].data_ptr(), x["lsi"].data_ptr(), x["loc"].data_ptr(),
+                                         x["attn"].data_ptr(), N, S, M, D, 4, S, 4, out.data_ptr(),
+                                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0 and lib.last_kernel("forward") == "msda_fwd_lg3"
+    ref = _fwd(MSDA, lib, x, "msda_fwd_lg3")
+    assert torch.equal(out, ref)
+    # value with 40 trailing rows that belong to no level: every query must still be computed
+    pad = 40
+    xv = dict(x)
+    xv["value"] = torch.cat([x["value"], torch.randn(N, pad, M, D, device=dev)], 1).contiguous()
+    xv["loc"] = torch.cat([x["loc"], torch.rand(N, pad, M, 4, 4, 2, device=dev)], 1).contiguous()
+    xv["attn"] = torch.cat([x["attn"], torch.softmax(torch.randn(N, pad, M, 16, device=dev), -1).view(N, pad, M, 4, 4)], 1).contiguous()
+    with ext.call_site(45):
+        o = _fwd(MSDA, lib, xv, "auto")
+    assert lib.last_kernel("forward") == "msda_fwd_lg3"
+    from oracle import msda_oracle
+    want = msda_oracle.forward(xv["value"], xv["shapes"], xv["lsi"], xv["loc"], xv["attn"])
+    assert float(np.abs(o.cpu().numpy().astype(np.float64) - want).max()) < 1e-4
+    torch.use_deterministic_algorithms(True)
+    try:
+        with ext.call_site(46):
+            _fwd(MSDA, lib, x, "auto")
+        assert lib.last_kernel("forward") == "msda_fwd_lg3"
+    finally:
+        torch.use_deterministic_algorithms(False)
 
 
 def test_window_forward_falls_back_outside_its_geometry(dev, api):
@@ -266,10 +332,10 @@ print("KERNELS", captured_kernel, eager_kernel, _lib.forward_locality()[0])
     res = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     line = [l for l in res.stdout.splitlines() if l.startswith("KERNELS")][0].split()
-    assert line[1] == "msda_fwd_lg3" and line[2] == "msda_fwd_win" and int(line[3]) == 1, line
+    assert line[1] == "msda_fwd_lg3" and line[2] == "msda_fwd_win" and int(line[3]) == 1, line   # captured: gather; eager: window, 1 report
 
 
-@pytest.mark.parametrize("variant", ["auto", "msda_fwd_win", "msda_fwd_lg3", "msda_fwd_lanegroup"])
+@pytest.mark.parametrize("variant", ["auto", "msda_fwd_win", "msda_fwd_win2", "msda_fwd_lg3", "msda_fwd_lanegroup"])
 def test_encoder_shaped_reference_fixture_forward(variant, dev, api):
     """Every kernel an encoder-shaped call can take, against the REFERENCE's own output for that shape
     (tests/golden/encshape_s1065_m2.npz, minted by ms_deform_attn_core_pytorch in float64): abs 1e-4."""
@@ -316,9 +382,10 @@ def test_encoder_kernels_on_other_batch_sizes_and_head_counts(heads, batch, dev,
     levels = ((25, 42), (13, 21), (7, 11), (4, 6))
     x = workloads.make_inputs("encoder", "model", batch=batch, levels=levels, heads=heads, seed=50 + heads, device=dev)
     ref = msda_oracle.forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
-    out = _fwd(MSDA, lib, x, "msda_fwd_win")
-    assert lib.last_kernel("forward") == "msda_fwd_win"
-    assert float(np.abs(out.cpu().numpy().astype(np.float64) - ref).max()) < 1e-4
+    for kernel in ("msda_fwd_win", "msda_fwd_win2"):
+        out = _fwd(MSDA, lib, x, kernel)
+        assert lib.last_kernel("forward") == kernel
+        assert float(np.abs(out.cpu().numpy().astype(np.float64) - ref).max()) < 1e-4, kernel
     S = x["value"].shape[1]
     go = torch.randn(batch, S, heads * 32, generator=torch.Generator().manual_seed(7)).to(dev)
     gv, gl, ga = MSDA.ms_deform_attn_backward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], go, 64)
@@ -344,10 +411,11 @@ def test_window_forward_far_path_with_odd_head_counts(heads, flavour, dev, api):
     kw = dict(flavour="model", offset_sigma=6.0) if flavour == "wide" else dict(flavour=flavour)
     for levels in (ODD_PYRAMIDS[2], ODD_PYRAMIDS[4]):
         x = workloads.make_inputs("encoder", batch=2, levels=levels, heads=heads, seed=60 + heads, device=dev, **kw)
-        out = _fwd(MSDA, lib, x, "msda_fwd_win")
-        assert lib.last_kernel("forward") == "msda_fwd_win"
         ref = msda_oracle.forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
-        assert float(np.abs(out.cpu().numpy().astype(np.float64) - ref).max()) < 1e-4, (levels, heads)
+        for kernel in ("msda_fwd_win", "msda_fwd_win2"):
+            out = _fwd(MSDA, lib, x, kernel)
+            assert lib.last_kernel("forward") == kernel
+            assert float(np.abs(out.cpu().numpy().astype(np.float64) - ref).max()) < 1e-4, (levels, heads, kernel)
 
 
 @pytest.mark.parametrize("head_major", [False, True])

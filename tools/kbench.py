@@ -43,15 +43,22 @@ def main():
     ap.add_argument("--sigma", type=float, default=1.0)
     ap.add_argument("--far", type=float, default=0.05)
     ap.add_argument("--rotate", type=int, default=1, help="cycle through this many distinct input sets (cold caches)")
+    ap.add_argument("--workloads", default="", help="comma list of named workloads (uninext_amd.workloads.WORKLOADS, or 'all') "
+                    "instead of --kinds at the R50 inference shapes")
     args = ap.parse_args()
     _lib.load()
     vf = [int(v) for v in args.variants_fwd.split(",") if v] or list(range(1, len(_lib.variants("forward"))))
     vb = [int(v) for v in args.variants_bwd.split(",") if v] or [1, 2, 3]
-    for kind in args.kinds.split(","):
+    names = list(workloads.WORKLOADS) if args.workloads == "all" else [w for w in args.workloads.split(",") if w]
+    for kind in (names or args.kinds.split(",")):
         for flavour in args.flavours.split(","):
             fl, sigma = ("model", 6.0) if flavour == "wide" else (flavour, args.sigma)
-            xs = [workloads.make_inputs(kind, fl, batch=args.batch, seed=1 + r, offset_sigma=sigma,
-                                        far_fraction=args.far) for r in range(args.rotate)]
+            if names:
+                xs = [workloads.make_workload(kind, fl, seed=1 + r, offset_sigma=sigma, far_fraction=args.far)
+                      for r in range(args.rotate)]
+            else:
+                xs = [workloads.make_inputs(kind, fl, batch=args.batch, seed=1 + r, offset_sigma=sigma,
+                                            far_fraction=args.far) for r in range(args.rotate)]
             x = xs[0]
             N, S = x["value"].shape[:2]
             Lq = x["loc"].shape[1]
@@ -66,7 +73,7 @@ def main():
             for v in vf:
                 _lib.set_variant("forward", v)
                 us = timeit(fwd_rot, args.reps)
-                print("fwd %-8s %-8s %-22s %9.1f us  %8.1f GB/s  %5.1f%% of 8TB/s" % (
+                print("fwd %-22s %-8s %-22s %9.1f us  %8.1f GB/s  %5.1f%% of 8TB/s" % (
                     kind, flavour, _lib.last_kernel("forward") + "#%d" % v, us, fb / us / 1e3, fb / us / 1e3 / 80), flush=True)
             _lib.set_variant("forward", 0)
             if args.no_bwd:
@@ -76,7 +83,7 @@ def main():
             for v in vb:
                 _lib.set_variant("backward", v)
                 us = timeit(lambda: ext.ms_deform_attn_backward(*a, go, 64), max(3, args.reps // 3))
-                print("bwd %-8s %-8s %-22s %9.1f us  %8.1f GB/s  %5.1f%% of 8TB/s (incl. grad_value memset)" % (
+                print("bwd %-22s %-8s %-22s %9.1f us  %8.1f GB/s  %5.1f%% of 8TB/s (incl. grad_value memset)" % (
                     kind, flavour, _lib.last_kernel("backward") + "#%d" % v, us, bb / us / 1e3, bb / us / 1e3 / 80), flush=True)
             _lib.set_variant("backward", 0)
 

@@ -14,7 +14,7 @@ EXPORTS = (
     "msda_hip_forward_fused_f32", "msda_hip_forward_fused_hm_f32",
     "msda_host_forward_f32", "msda_host_forward_f64", "msda_host_backward_f32", "msda_host_backward_f64",
     "msda_hip_set_variant", "msda_hip_get_variant", "msda_hip_variant_name", "msda_hip_last_kernel",
-    "msda_hip_forward_locality",
+    "msda_hip_forward_locality", "msda_hip_set_call_context",
 )
 
 DYNMASK_EXPORTS = ("dynmask_hip_forward_f32", "aligned_bilinear_hip_f32", "dynmask_hip_set_variant",
@@ -99,6 +99,7 @@ def load():
     lib.msda_hip_variant_name.argtypes, lib.msda_hip_variant_name.restype = [i, i], s
     lib.msda_hip_last_kernel.argtypes, lib.msda_hip_last_kernel.restype = [i], s
     lib.msda_hip_forward_locality.argtypes, lib.msda_hip_forward_locality.restype = [ctypes.POINTER(ctypes.c_double)], i
+    lib.msda_hip_set_call_context.argtypes, lib.msda_hip_set_call_context.restype = [i, ctypes.c_uint], None
     got = lib.msda_hip_abi_version()
     if got != ABI_VERSION:
         raise RuntimeError("libmsda_hip.so ABI version %d, binding expects %d: rebuild" % (got, ABI_VERSION))
@@ -131,7 +132,8 @@ def variants(which):
 
 
 def forward_locality():
-    """(reports so far, far fraction of the latest) of the window kernel's locality statistic (include/msda_hip.h)."""
+    """(reports consumed so far, far fraction of the latest) on the call site used last (include/msda_hip.h); waits for the
+    launches made so far on that site."""
     frac = ctypes.c_double(0.0)
     n = load().msda_hip_forward_locality(ctypes.byref(frac))
     return n, frac.value

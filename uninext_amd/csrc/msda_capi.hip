@@ -181,6 +181,8 @@ const char* msda_hip_variant_name(int which, int variant) {
 
 int msda_hip_forward_locality(double* far_fraction) { return msda::forward_locality(far_fraction); }
 
+void msda_hip_set_call_context(int call_site, unsigned flags) { msda::set_call_context(call_site, flags); }
+
 const char* msda_hip_last_kernel(int which) {
   return (which < 0 || which > 1) ? "" : g_last_kernel[which].load(std::memory_order_relaxed);
 }

@@ -116,7 +116,9 @@ int launch_backward_tiled(const float* grad_out, const float* value, const int64
 
 // msda_fwd_win.hip: encoder forward with LDS windows on all four levels (fp32, D = 32, L = P = 4, Lq == S).
 bool win_forward_ok(const Dims& d);
-bool win_forward_auto(const Dims& d, hipStream_t stream);   // auto dispatch: take the window kernel for this call?
+bool win_forward_auto(const Dims& d, hipStream_t stream);   // auto dispatch: take the window kernel for this call? (consumes the call context)
+void set_call_context(int slot, unsigned flags);            // include/msda_hip.h: msda_hip_set_call_context
+void drop_call_context();
 int launch_forward_win_fused(const float* value, int head_major, const int64_t* shapes, const int64_t* lsi,
                              const float* ref_points, int ref_dim, const float* offsets, const float* logits, const Dims& d,
                              float* out, hipStream_t stream);

@@ -316,6 +316,7 @@ int launch_forward_fused(int variant, const float* value, int head_major, const 
   static const bool use_lg3 = !(std::getenv("MSDA_HIP_FUSED_LG3") && std::getenv("MSDA_HIP_FUSED_LG3")[0] == '0');
   // encoder-shaped calls: the LDS-window kernel with the prologue folded in while the samples are local (variant 0
   // follows the locality report like the operator does; variants 9 / 7 pin the window / the gather kernel)
+  if (variant != kAuto) drop_call_context();
   if (win_forward_ok(d) && (variant == kWin || (variant == kAuto && win_forward_auto(d, stream)))) {
     *kernel_name = "msda_fwd_win_fused";
     return launch_forward_win_fused(value, head_major, shapes, lsi, ref_points, ref_dim, offsets, logits, d, out, stream);
@@ -946,6 +947,7 @@ int launch_forward<float>(int variant, const float* value, const int64_t* shapes
   // ... and the LDS-window kernel beats msda_fwd_lg3 on the encoder shape while the samples stay near their queries:
   // win_forward_auto follows the locality the window kernel itself reported for the latest launches
   if (variant == kAuto) variant = win_forward_auto(d, stream) ? kWin : (lg3_ok(d) ? kLaneGroupL3 : (lg ? kLaneGroup : kGeneric));
+  else drop_call_context();
   if (variant == kWin2 && !win2_forward_ok(d)) variant = lg3_ok(d) ? kLaneGroupL3 : kLaneGroup;
   if (variant == kWin2) {
     *kernel_name = "msda_fwd_win2";

@@ -56,7 +56,7 @@ constexpr int kT = 512, kWaves = kT / 64, kQuads = kT / 4;
 // (bench flavours: far 0.02 -> 78 us against 107 for msda_fwd_lg3, 0.41 -> 147 against 101-123, 0.93 -> 184 against
 // 106-121: the lines cross near 0.2), and the statistic is refreshed every kReprobe-th call otherwise
 constexpr double kFarFractionMax = 0.20;
-constexpr unsigned kReprobe = 64;
+constexpr unsigned kReprobe = 64, kReportEvery = 8;
 constexpr int kTH = 8, kTW = 16;
 constexpr int kWH[4] = {14, 10, 8, 7};
 constexpr int kWW[4] = {22, 14, 10, 8};                         // even: slot parity == column parity in every row
@@ -123,14 +123,16 @@ struct Smp {
 };
 
 // Locality statistic: how many in-range samples of a launch missed their tile's windows.  Accumulated in device
-// memory, moved by the last workgroup of the launch to a host-mapped report the dispatcher reads without a sync.
-// one word, in device memory while a launch runs and (with the report number in place of the ticket) in the
-// host-mapped report: far samples (bits 0..25), live (query, head) pairs (26..47), sampled workgroups done (48..63)
-struct LocalityCounters { unsigned long long packed; volatile unsigned long long* report; unsigned seq, pad; };
+// memory, moved by the last workgroup of the launch to a host-mapped report the dispatcher reads once the launch is
+// known to be complete.  One word, in device memory while a launch runs and (with the launch's sequence number in
+// place of the ticket) in the host-mapped report: far samples (bits 0..25), live (query, head) pairs (26..47),
+// sampled workgroups done / sequence number (48..63).  EVERY LAUNCH HAS ITS OWN counter and report word (a ring per
+// call-site slot, see locality_state below): launches that overlap on different streams, or a graph replay next to
+// eager calls, cannot mix their counts.
+struct LocalityArgs { unsigned long long* counter; volatile unsigned long long* report; unsigned seq, pad; };
 constexpr int kStatPairShift = 26, kStatTicketShift = 48;
 // every 2^shift-th workgroup of a head is sampled: 1 in 16, fewer on launches of more than 65536 workgroups (the
 // fields above hold 4096 sampled workgroups of <= 192 pairs)
-__device__ LocalityCounters g_locality;     // .report is set by the host once per device (locality_state)
 __device__ __forceinline__ int stat_shift(int workgroups) {
   int sh = 4;
   while ((workgroups >> sh) > 4096) ++sh;
@@ -153,7 +155,8 @@ template <int DMA_AUX, bool STAT, int REFD>   // DMA_AUX: cache policy bits of t
 __device__ __forceinline__ void win_body(const float* __restrict__ value, const int64_t* __restrict__ shapes,
                                          const int64_t* __restrict__ lsi, const float* __restrict__ loc,
                                          const float* __restrict__ attn, const Dims& d, float* __restrict__ out,
-                                         const float* __restrict__ ref_points, const bool head_major) {
+                                         const float* __restrict__ ref_points, const bool head_major,
+                                         const LocalityArgs& la) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Meta& mt = *reinterpret_cast<Meta*>(smem + kMetaOff);
   const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -627,20 +630,17 @@ __device__ __forceinline__ void win_body(const float* __restrict__ value, const 
   // atomics from all XCDs cost ~14 ns each, 3000 of them would double the kernel's time) -> host (the last sampled
   // workgroup stores the totals into host-mapped memory) ----------------------------------------------------------------
   if (STAT && lane == 0) {
-    LocalityCounters* const gstat = &g_locality;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (atomicAdd(&mt.stat[2], 1) == kWaves - 1) {             // the last wave of the workgroup
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       const unsigned long long mine = (unsigned long long)(unsigned)atomicAdd(&mt.stat[0], 0) |
                                       ((unsigned long long)(unsigned)mt.stat[1] << kStatPairShift) | (1ull << kStatTicketShift);
-      const unsigned long long now = atomicAdd(&gstat->packed, mine) + mine;
+      const unsigned long long now = atomicAdd(la.counter, mine) + mine;
       const unsigned expected = (unsigned)mt.stat[3];
       if ((unsigned)(now >> kStatTicketShift) == expected) {      // the last sampled workgroup of the launch
-        atomicExch(&gstat->packed, 0ull);
+        atomicExch(la.counter, 0ull);                           // this ring entry's next launch starts from zero
         // ONE 8-byte store into host-mapped memory: no system-scope fence (it would write the L2 back), no read over PCIe
-        const unsigned seq = gstat->seq + 1u;
-        gstat->seq = seq;
-        *gstat->report = (now & ((1ull << kStatTicketShift) - 1ull)) | ((unsigned long long)(seq & 0xffffu) << kStatTicketShift);
+        *la.report = (now & ((1ull << kStatTicketShift) - 1ull)) | ((unsigned long long)(la.seq & 0xffffu) << kStatTicketShift);
       }
     }
   }
@@ -657,12 +657,12 @@ __device__ __forceinline__ bool win_sampled(const int64_t* __restrict__ shapes, 
 template <int DMA_AUX, bool STAT>
 __global__ void __launch_bounds__(kT, 4)
 msda_fwd_win(const float* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
-             const float* __restrict__ loc, const float* __restrict__ attn, Dims d, float* __restrict__ out) {
+             const float* __restrict__ loc, const float* __restrict__ attn, Dims d, float* __restrict__ out, LocalityArgs la) {
   if (STAT && win_sampled(shapes, d)) {
-    win_body<DMA_AUX, true, 0>(value, shapes, lsi, loc, attn, d, out, nullptr, false);
+    win_body<DMA_AUX, true, 0>(value, shapes, lsi, loc, attn, d, out, nullptr, false, la);
     return;
   }
-  win_body<DMA_AUX, false, 0>(value, shapes, lsi, loc, attn, d, out, nullptr, false);
+  win_body<DMA_AUX, false, 0>(value, shapes, lsi, loc, attn, d, out, nullptr, false, la);
 }
 
 // the module's inference path: prologue folded in (REFD = 2 / 4), value in the reference or the head-major layout
@@ -670,12 +670,12 @@ template <bool STAT, int REFD>
 __global__ void __launch_bounds__(kT, 4)
 msda_fwd_win_fused(const float* __restrict__ value, int head_major, const int64_t* __restrict__ shapes,
                    const int64_t* __restrict__ lsi, const float* __restrict__ ref_points, const float* __restrict__ offsets,
-                   const float* __restrict__ logits, Dims d, float* __restrict__ out) {
+                   const float* __restrict__ logits, Dims d, float* __restrict__ out, LocalityArgs la) {
   if (STAT && win_sampled(shapes, d)) {
-    win_body<0, true, REFD>(value, shapes, lsi, offsets, logits, d, out, ref_points, head_major != 0);
+    win_body<0, true, REFD>(value, shapes, lsi, offsets, logits, d, out, ref_points, head_major != 0, la);
     return;
   }
-  win_body<0, false, REFD>(value, shapes, lsi, offsets, logits, d, out, ref_points, head_major != 0);
+  win_body<0, false, REFD>(value, shapes, lsi, offsets, logits, d, out, ref_points, head_major != 0, la);
 }
 
 #ifdef MSDA_WIN_PROF
@@ -695,92 +695,199 @@ bool win_forward_ok(const Dims& d) {
 
 namespace {
 
-// Per-device locality state: the counters the kernel accumulates into, the host-mapped report its last workgroup
-// writes, and the dispatcher's bookkeeping.  Everything here is advisory -- it picks a kernel, never a result.
+// ---- automatic choice between msda_fwd_win and msda_fwd_lg3 (variant 0 on the encoder shape) -----------------------
+// The window kernel wins while the samples of a tile stay near it and loses (up to 1.7x) when they do not, and only the
+// locations know which.  Every STAT launch of the window kernel reports the far fraction of its own inputs.
+//
+//   per call site   The state is kept per SLOT (msda_hip_set_call_context: the MSDeformAttn module passes its own, the
+//                   bare operator uses slot 0): six encoder layers of a trained checkpoint need not share one locality.
+//   per launch      A slot owns a ring of kRing (counter, report) pairs; launch n of the slot uses entry n % kRing and
+//                   tags its report with n -- overlapping launches (other streams, graph replays) cannot mix counts.
+//   deterministic   The report of launch n is consumed at the slot's SECOND call after it, behind a wait on the event
+//                   recorded after that launch (normally long complete, so the wait costs nothing; a host running far
+//                   ahead is throttled to two window launches per slot).  The kernel a call takes is therefore a function
+//                   of the call sequence alone -- never of whether a report happened to land in time -- and two runs of
+//                   the same script give bitwise equal results.
+//   pinned          No context, geometry not vouched for (window kernels need sum H_l W_l == spatial_size, include/
+//                   msda_hip.h), MSDA_CTX_DETERMINISTIC, MSDA_HIP_FWD_ADAPTIVE=0 or a stream capture in progress (events
+//                   cannot be waited for inside one): the gather kernel.
+constexpr int kSites = 64, kRing = 4, kLag = 2;
+struct Slot {
+  std::mutex mu;
+  int mode = 0;                          // 0: nothing known yet (window kernel, reporting), 1: window kernel, 2: gather kernel
+  unsigned calls = 0;                    // auto-dispatched calls on this slot
+  unsigned seq = 0;                      // STAT launches so far; launch n (1-based) uses ring entry n % kRing
+  unsigned consumed = 0;                 // reports consumed so far (== seq of the last one)
+  unsigned launch_call[kRing] = {};      // the call number of the launch in each ring entry
+  unsigned since_probe = 0;
+  double far = 0.0;
+  hipEvent_t ev[kRing] = {};
+};
 struct LocalityState {
-  volatile unsigned long long* report = nullptr;   // pinned host memory, mapped into the device: the latest report
-  unsigned long long* report_dev = nullptr;        // the device's address of `report`
-  unsigned reports = 0, last_seq = 0;              // reports seen by forward_locality (the word carries 16 bits of it)
-  std::atomic<unsigned> since_probe{0};     // auto-dispatched calls on the other kernel since the last window launch
+  volatile unsigned long long* report = nullptr;   // pinned host memory, mapped into the device: [kSites][kRing]
+  unsigned long long* report_dev = nullptr;        // the device's address of it
+  unsigned long long* counters = nullptr;          // device memory: [kSites][kRing]
+  Slot slots[kSites];
+  int last_slot = 0;                               // msda_hip_forward_locality reports the slot used last
 };
 constexpr int kMaxDevices = 64;
-LocalityState g_loc[kMaxDevices];
+LocalityState* g_loc[kMaxDevices];
 std::atomic<int> g_loc_ready[kMaxDevices];
 std::mutex g_loc_mutex;
+
+bool capturing(hipStream_t stream) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  return stream && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+}
 
 LocalityState* locality_state(hipStream_t stream) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
-  if (g_loc_ready[dev].load(std::memory_order_acquire) == 1) return &g_loc[dev];
-  // first use on this device: allocates and copies -- not inside a stream capture (the caller then runs without the
-  // statistic: the plain copy of the kernel, or msda_fwd_lg3 under variant 0)
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (stream && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return nullptr;
+  if (g_loc_ready[dev].load(std::memory_order_acquire) == 1) return g_loc[dev];
+  if (capturing(stream)) return nullptr;        // first use allocates and clears: not inside a stream capture
   std::lock_guard<std::mutex> lock(g_loc_mutex);
-  if (g_loc_ready[dev].load(std::memory_order_relaxed) == 1) return &g_loc[dev];
+  if (g_loc_ready[dev].load(std::memory_order_relaxed) == 1) return g_loc[dev];
   if (g_loc_ready[dev].load(std::memory_order_relaxed) == -1) return nullptr;
-  LocalityState& st = g_loc[dev];
+  LocalityState* st = new LocalityState();
   void* rp = nullptr;
-  LocalityCounters init{};
-  init.packed = 0;
-  init.seq = 0;
-  if (hipHostMalloc(&rp, sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess ||
-      hipHostGetDevicePointer(reinterpret_cast<void**>(&st.report_dev), rp, 0) != hipSuccess ||
-      (init.report = st.report_dev, init.pad = 0, hipMemcpyToSymbol(HIP_SYMBOL(g_locality), &init, sizeof(init), 0, hipMemcpyHostToDevice)) != hipSuccess) {
+  const size_t bytes = sizeof(unsigned long long) * kSites * kRing;
+  bool ok = hipHostMalloc(&rp, bytes, hipHostMallocMapped) == hipSuccess &&
+            hipHostGetDevicePointer(reinterpret_cast<void**>(&st->report_dev), rp, 0) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&st->counters), bytes) == hipSuccess &&
+            hipMemset(st->counters, 0, bytes) == hipSuccess;
+  for (int i = 0; ok && i < kSites; ++i)
+    for (int r = 0; ok && r < kRing; ++r) ok = hipEventCreateWithFlags(&st->slots[i].ev[r], hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
     (void)hipGetLastError();
     g_loc_ready[dev].store(-1, std::memory_order_relaxed);
-    return nullptr;
+    return nullptr;                              // (leaks what was allocated: once per process, on a failing device)
   }
-  st.report = static_cast<volatile unsigned long long*>(rp);
-  *st.report = 0ull;
+  st->report = static_cast<volatile unsigned long long*>(rp);
+  std::memset(rp, 0, bytes);
+  g_loc[dev] = st;
   g_loc_ready[dev].store(1, std::memory_order_release);
-  return &st;
+  return st;
 }
+
+struct CallContext { int slot = -1; unsigned flags = 0; bool set = false; };
+thread_local CallContext t_ctx;
+
+// what the launchers below need to know about the call that is being dispatched (set by win_forward_auto)
+struct Pending { LocalityState* st = nullptr; int slot = -1; bool stat = false; };
+thread_local Pending t_pending;
 
 }  // namespace
 
-int forward_locality(double* far_fraction) {
-  LocalityState* st = locality_state(nullptr);
-  if (!st) return 0;
-  const unsigned long long w = *st->report;
-  const unsigned long long f = w & ((1ull << kStatPairShift) - 1ull);
-  const unsigned long long n = 16ull * ((w >> kStatPairShift) & ((1ull << (kStatTicketShift - kStatPairShift)) - 1ull));
-  if (far_fraction) *far_fraction = n ? (double)f / (double)n : 0.0;
-  const unsigned seq = (unsigned)(w >> kStatTicketShift);
-  {  // widen the 16-bit report number (advisory; a racing reader may count a report twice)
-    std::lock_guard<std::mutex> lock(g_loc_mutex);
-    st->reports += (seq - st->last_seq) & 0xffffu;
-    st->last_seq = seq;
-    return (int)st->reports;
-  }
+void set_call_context(int slot, unsigned flags) {
+  t_ctx.slot = slot;
+  t_ctx.flags = flags;
+  t_ctx.set = true;
 }
 
-// auto dispatch of the encoder shape: window kernel or msda_fwd_lg3?  The window kernel wins while the samples of a
-// tile stay near it and loses (up to 1.7x) when they do not, and only the locations know which.  Every launch of the
-// window kernel reports the far fraction of its own inputs; the next calls follow the latest report, and while they
-// run the other kernel every kReprobe-th call goes through the window kernel again to refresh it.
+void drop_call_context() {                       // a call that does not dispatch automatically still consumes its context
+  t_ctx = CallContext();
+  t_pending = Pending();
+}
+
+int forward_locality(double* far_fraction) {
+  LocalityState* st = locality_state(nullptr);
+  if (far_fraction) *far_fraction = 0.0;
+  if (!st) return 0;
+  Slot& sl = st->slots[st->last_slot];
+  std::lock_guard<std::mutex> lock(sl.mu);
+  // everything launched so far on the slot (the caller asks after a synchronisation; an event that is not complete yet
+  // is waited for -- this is a diagnostic entry point, not the dispatcher)
+  while (sl.consumed < sl.seq) {
+    const unsigned n = sl.consumed + 1;
+    if (hipEventSynchronize(sl.ev[n % kRing]) != hipSuccess) { (void)hipGetLastError(); break; }
+    const unsigned long long w = st->report[st->last_slot * kRing + n % kRing];
+    if ((unsigned)(w >> kStatTicketShift) == (n & 0xffffu)) {
+      const unsigned long long f = w & ((1ull << kStatPairShift) - 1ull);
+      const unsigned long long pairs = 16ull * ((w >> kStatPairShift) & ((1ull << (kStatTicketShift - kStatPairShift)) - 1ull));
+      sl.far = pairs ? (double)f / (double)pairs : 0.0;
+      sl.mode = sl.far <= kFarFractionMax ? 1 : 2;
+    }
+    sl.consumed = n;
+  }
+  if (far_fraction) *far_fraction = sl.far;
+  return (int)sl.consumed;
+}
+
+// auto dispatch of the encoder shape: window kernel or msda_fwd_lg3?  Consumes the thread's call context.
 bool win_forward_auto(const Dims& d, hipStream_t stream) {
-  static const int mode = [] { const char* e = std::getenv("MSDA_HIP_FWD_ADAPTIVE"); return e ? std::atoi(e) : 1; }();
-  if (mode == 0 || !win_forward_ok(d)) return false;
+  static const int mode_env = [] { const char* e = std::getenv("MSDA_HIP_FWD_ADAPTIVE"); return e ? std::atoi(e) : 1; }();
+  const CallContext ctx = t_ctx;
+  t_ctx = CallContext();
+  t_pending = Pending();
+  if (mode_env == 0 || !ctx.set || ctx.slot < 0 || ctx.slot >= kSites || !(ctx.flags & 1u) || (ctx.flags & 2u) ||
+      !win_forward_ok(d) || capturing(stream))
+    return false;
   LocalityState* st = locality_state(stream);
   if (!st) return false;
-  double far = 0.0;
-  const int seq = forward_locality(&far);
-  if (seq == 0 || far <= kFarFractionMax) { st->since_probe.store(0, std::memory_order_relaxed); return true; }
-  if (st->since_probe.fetch_add(1, std::memory_order_relaxed) + 1 >= kReprobe) {
-    st->since_probe.store(0, std::memory_order_relaxed);
-    return true;
+  Slot& sl = st->slots[ctx.slot];
+  std::lock_guard<std::mutex> lock(sl.mu);
+  st->last_slot = ctx.slot;
+  sl.calls += 1;
+  // consume the reports that are due: launched at least kLag calls ago on this slot
+  while (sl.consumed < sl.seq && sl.calls - sl.launch_call[(sl.consumed + 1) % kRing] >= (unsigned)kLag) {
+    const unsigned n = sl.consumed + 1;
+    if (hipEventSynchronize(sl.ev[n % kRing]) != hipSuccess) { (void)hipGetLastError(); break; }
+    const unsigned long long w = st->report[ctx.slot * kRing + n % kRing];
+    if ((unsigned)(w >> kStatTicketShift) == (n & 0xffffu)) {     // (a launch that failed leaves its word stale: ignored)
+      const unsigned long long f = w & ((1ull << kStatPairShift) - 1ull);
+      const unsigned long long pairs = 16ull * ((w >> kStatPairShift) & ((1ull << (kStatTicketShift - kStatPairShift)) - 1ull));
+      sl.far = pairs ? (double)f / (double)pairs : 0.0;
+      const int mode = sl.far <= kFarFractionMax ? 1 : 2;
+      if (mode != sl.mode) sl.since_probe = 0;
+      sl.mode = mode;
+    }
+    sl.consumed = n;
   }
-  return false;
+  bool window, report;
+  if (sl.mode == 2) {                            // gather kernel, with every kReprobe-th call through the window kernel
+    sl.since_probe += 1;
+    window = report = sl.since_probe >= kReprobe;
+    if (window) sl.since_probe = 0;
+  } else {                                       // window kernel; while nothing is known every launch reports, afterwards
+    window = true;                               // every kReportEvery-th (the counting copy + the event cost ~2 % of a launch)
+    report = sl.mode == 0 || sl.since_probe == 0;
+    sl.since_probe = sl.mode == 0 ? 0 : (sl.since_probe + 1) % kReportEvery;
+  }
+  // (a ring entry still waiting to be consumed is never reused: cannot happen with kLag < kRing)
+  const bool stat = report && sl.seq - sl.consumed < (unsigned)kRing - 1u;
+  t_pending.st = st;
+  t_pending.slot = ctx.slot;
+  t_pending.stat = stat;
+  return window;
 }
+
+namespace {
+// the (counter, report, sequence number) of the STAT launch that is about to be made for the pending auto-dispatched
+// call, and the event to record behind it; a pinned window launch (variant 9) reports nothing
+bool begin_stat_launch(LocalityArgs* la, hipEvent_t* ev) {
+  *la = LocalityArgs{nullptr, nullptr, 0u, 0u};
+  const Pending p = t_pending;
+  t_pending = Pending();
+  if (!p.st || !p.stat) return false;
+  Slot& sl = p.st->slots[p.slot];
+  std::lock_guard<std::mutex> lock(sl.mu);
+  const unsigned n = ++sl.seq;
+  sl.launch_call[n % kRing] = sl.calls;
+  la->counter = p.st->counters + (p.slot * kRing + n % kRing);
+  la->report = p.st->report_dev + (p.slot * kRing + n % kRing);
+  la->seq = n;
+  *ev = sl.ev[n % kRing];
+  return true;
+}
+}  // namespace
 
 int launch_forward_win(const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc, const float* attn,
                        const Dims& d, float* out, hipStream_t stream) {
   static const bool nt = std::getenv("MSDA_WIN_NT") && std::getenv("MSDA_WIN_NT")[0] == '1';   // A/B switch
   static std::atomic<uint64_t> lds_opted_in[3] = {{0}, {0}, {0}};
-  static const bool stat_env = !(std::getenv("MSDA_WIN_STAT") && std::getenv("MSDA_WIN_STAT")[0] == '0');   // A/B switch
-  // the counting copy of the kernel writes its report through g_locality.report: only once that is set up
-  const bool stat = stat_env && locality_state(stream) != nullptr;
+  LocalityArgs la;
+  hipEvent_t ev = nullptr;
+  const bool stat = begin_stat_launch(&la, &ev);
   const auto kern = stat ? (nt ? msda_fwd_win<2, true> : msda_fwd_win<0, true>) : msda_fwd_win<0, false>;
   const void* fn = reinterpret_cast<const void*>(kern);
   if (int rc = ensure_dynamic_lds(fn, kLdsBytes, lds_opted_in[stat ? (nt ? 1 : 0) : 2])) return rc;
@@ -794,16 +901,19 @@ int launch_forward_win(const float* value, const int64_t* shapes, const int64_t*
   int K = persist ? (2 * 256) / d.M : d.N * ((d.S + 127) / 128);
   if (K < 1) K = 1;
   const dim3 grid((unsigned)(d.M * K), 1u);
-  hipLaunchKernelGGL(kern, grid, dim3(kT), kLdsBytes, stream, value, shapes, lsi, loc, attn, d, out);
-  return (int)hipGetLastError();
+  hipLaunchKernelGGL(kern, grid, dim3(kT), kLdsBytes, stream, value, shapes, lsi, loc, attn, d, out, la);
+  const int rc = (int)hipGetLastError();
+  if (stat && rc == 0) (void)hipEventRecord(ev, stream);
+  return rc;
 }
 
 int launch_forward_win_fused(const float* value, int head_major, const int64_t* shapes, const int64_t* lsi,
                              const float* ref_points, int ref_dim, const float* offsets, const float* logits, const Dims& d,
                              float* out, hipStream_t stream) {
   static std::atomic<uint64_t> lds_opted_in[4] = {{0}, {0}, {0}, {0}};
-  static const bool stat_env = !(std::getenv("MSDA_WIN_STAT") && std::getenv("MSDA_WIN_STAT")[0] == '0');
-  const bool stat = stat_env && locality_state(stream) != nullptr;
+  LocalityArgs la;
+  hipEvent_t ev = nullptr;
+  const bool stat = begin_stat_launch(&la, &ev);
   const auto kern = ref_dim == 2 ? (stat ? msda_fwd_win_fused<true, 2> : msda_fwd_win_fused<false, 2>)
                                  : (stat ? msda_fwd_win_fused<true, 4> : msda_fwd_win_fused<false, 4>);
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), kLdsBytes, lds_opted_in[(ref_dim == 2 ? 0 : 2) + (stat ? 1 : 0)]))
@@ -811,8 +921,10 @@ int launch_forward_win_fused(const float* value, int head_major, const int64_t* 
   int K = d.N * ((d.S + 127) / 128);                        // as in launch_forward_win
   if (K < 1) K = 1;
   hipLaunchKernelGGL(kern, dim3((unsigned)(d.M * K), 1u), dim3(kT), kLdsBytes, stream, value, head_major, shapes, lsi,
-                     ref_points, offsets, logits, d, out);
-  return (int)hipGetLastError();
+                     ref_points, offsets, logits, d, out, la);
+  const int rc = (int)hipGetLastError();
+  if (stat && rc == 0) (void)hipEventRecord(ev, stream);
+  return rc;
 }
 
 }  // namespace msda

@@ -745,14 +745,17 @@ int launch_forward_win2(const float* value, const int64_t* shapes, const int64_t
   // items kk, kk + K, ...  Head m = blockIdx.x, i.e. (by the observed round-robin placement of the linear workgroup id)
   // XCD m % 8 only ever touches head m's slice of `value` when M is a multiple of 8.
   int K = d.N * ((d.S + 127) / 128);
-  // MSDA_WIN2_PERSIST=n (A/B switch; default below): n > 0: n workgroups per head walk the items, -n: the same with the
-  // static stride instead of tickets, 0: one workgroup per item
+  // Default: a persistent grid of two resident workgroups per CU spread over the heads, static stride over the items
+  // (83.7-86.0 us against 90.4-93.1 for one workgroup per item: 4.4 us pass between a workgroup's last store and its successor's
+  // first instruction; per-head ticket counters LOSE to the static stride, 91.5 us -- profiles/r03_forward_window_analysis.txt).
+  // MSDA_WIN2_PERSIST=n (A/B switch): 0 = one workgroup per item, -n = n workgroups per head with the static stride,
+  // +n = n workgroups per head drawing tickets.
   static const int persist_env = std::getenv("MSDA_WIN2_PERSIST") ? std::atoi(std::getenv("MSDA_WIN2_PERSIST")) : kPersistDefault;
   int persist = persist_env;
-  if (persist == kPersistDefault) {                        // two resident workgroups per CU, spread over the heads
+  if (persist == kPersistDefault) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    persist = (2 * cus + d.M - 1) / d.M;
+    persist = -((2 * cus + d.M - 1) / d.M);
   }
   static std::atomic<unsigned> launch_seq{0};
   int ticket_set = -1;

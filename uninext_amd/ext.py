@@ -6,12 +6,15 @@ Reference host code mirrored: ops/src/ms_deform_attn.h:21-61 (device dispatch: C
 raise "Not implemented on the CPU") and ops/src/cuda/ms_deform_attn_cuda.cu:28-52
 (contiguity / device / im2col_step checks), :54 and :121-123 (output allocation).
 """
+import contextlib
 import ctypes
 import os
+import threading
 
 import torch
 
 from . import _lib
+from ._cache import CheckedOnce
 
 _SUFFIX = {torch.float32: "f32", torch.float64: "f64"}
 # CPU tensors: the reference raises "Not implemented on the CPU" (ops/src/ms_deform_attn.h:35-38).  This library has
@@ -21,6 +24,54 @@ _SUFFIX = {torch.float32: "f32", torch.float64: "f64"}
 # reference's error.  GPU tensors never take this route: they go to the HIP kernels or fail loudly.
 STRICT_DEVICE = os.environ.get("MSDA_HIP_STRICT_DEVICE", "0") == "1"
 HOST_THREADS = int(os.environ.get("MSDA_HOST_THREADS", "0"))   # 0: all hardware threads
+
+
+# ---- call context of the automatic forward-kernel choice (include/msda_hip.h: msda_hip_set_call_context) ----------------
+CTX_GEOMETRY_CHECKED, CTX_DETERMINISTIC = 1, 2
+_site = threading.local()
+_geometry_checks = CheckedOnce()
+
+
+@contextlib.contextmanager
+def call_site(site):
+    """Forward calls made inside the block belong to call site `site` (0..63): the library chooses between its two
+    encoder-forward kernels PER SITE.  MSDeformAttn modules wrap their operator calls in their own; the bare operator
+    uses site 0."""
+    prev = getattr(_site, "value", 0)
+    _site.value = int(site)
+    try:
+        yield
+    finally:
+        _site.value = prev
+
+
+def _geometry_checked(spatial_shapes, level_start_index, spatial_size):
+    """sum_l H_l * W_l == spatial_size and level_start_index == the prefix sums -- the precondition of the window kernels,
+    which the reference operator itself does not require.  A device -> host copy, done once per shapes TENSOR OBJECT (weak
+    reference + version, tests/test_cache_cpu.py) and never during a stream capture (a capture only sees earlier verdicts)."""
+    extra = (int(spatial_size), id(level_start_index), int(level_start_index.data_ptr()))
+    if _geometry_checks.hit(spatial_shapes, extra):
+        return True
+    if torch.cuda.is_current_stream_capturing():
+        return False
+    hw = (spatial_shapes[:, 0] * spatial_shapes[:, 1]).cpu()
+    lsi = level_start_index.cpu()
+    ok = bool((spatial_shapes.cpu() > 0).all()) and int(hw.sum()) == int(spatial_size) and lsi.shape[0] == hw.shape[0] \
+        and bool((lsi == torch.cat((hw.new_zeros(1), hw.cumsum(0)[:-1]))).all())
+    if ok:
+        _geometry_checks.add(spatial_shapes, extra)
+    return ok
+
+
+def _set_call_context(lib, value_dtype, spatial_shapes, level_start_index, S, M_D, L, Lq, P):
+    """Describe the coming forward call to the library.  Only encoder-shaped fp32 calls have a choice to make; for
+    everything else no context is set (and nothing is copied to the host)."""
+    if value_dtype != torch.float32 or Lq != S or S < 1024 or L != 4 or P != 4 or M_D != 32:
+        return
+    flags = CTX_GEOMETRY_CHECKED if _geometry_checked(spatial_shapes, level_start_index, S) else 0
+    if torch.are_deterministic_algorithms_enabled():
+        flags |= CTX_DETERMINISTIC
+    lib.msda_hip_set_call_context(int(getattr(_site, "value", 0)), flags)
 
 
 def _check(name, t, dev):
@@ -106,6 +157,7 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)  # kernel writes every element
     with torch.cuda.device(value.device):
         stream = torch.cuda.current_stream().cuda_stream
+        _set_call_context(lib, value.dtype, spatial_shapes, level_start_index, S, D, L, Lq, P)
         rc = getattr(lib, "msda_hip_forward_" + suf)(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
             attn_weight.data_ptr(), N, S, M, D, L, Lq, P, out.data_ptr(), ctypes.c_void_p(stream))
@@ -182,6 +234,7 @@ def ms_deform_attn_forward_fused(value, spatial_shapes, level_start_index, refer
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
     with torch.cuda.device(value.device):
         stream = torch.cuda.current_stream().cuda_stream
+        _set_call_context(lib, value.dtype, spatial_shapes, level_start_index, S, D, L, Lq, P)
         fn = lib.msda_hip_forward_fused_hm_f32 if value_head_major else lib.msda_hip_forward_fused_f32
         rc = fn(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), reference_points.data_ptr(),

@@ -75,6 +75,15 @@ class MSDeformAttn(CachedModuleMixin, nn.Module):
 
     # -- argument check of :93 without a device->host sync per call -----------------------------------------
     _shape_checks = CheckedOnce()
+    _instances = 0          # every instance is a call site of its own for the library's forward-kernel choice (sites 1..63)
+
+    def _site(self):
+        site = self.__dict__.get("_msda_site")
+        if site is None:
+            cls = MSDeformAttn
+            cls._instances += 1
+            site = self.__dict__["_msda_site"] = 1 + (cls._instances - 1) % 63
+        return site
 
     @classmethod
     def _check_shapes(cls, spatial_shapes, len_in):
@@ -210,16 +219,17 @@ class MSDeformAttn(CachedModuleMixin, nn.Module):
             value = value.view(N, Len_in, self.n_heads, head_dim)
         offsets, logits = self._project_offsets_and_logits(query, query_pos)          # (N, Lq, M*L*P*2), (N, Lq, M*L*P)
 
-        if head_major:
-            sampled = MSDA.ms_deform_attn_forward_fused(value, input_spatial_shapes, input_level_start_index,
-                                                        reference_points, offsets.contiguous(), logits.contiguous(),
-                                                        self.n_points, value_head_major=True)
-        elif self._can_fuse(value, reference_points, offsets, logits):
-            sampled = MSDA.ms_deform_attn_forward_fused(value, input_spatial_shapes, input_level_start_index,
-                                                        reference_points, offsets, logits, self.n_points)
-        else:
-            sampled = self._sample_autograd(value, input_spatial_shapes, input_level_start_index, reference_points,
-                                            offsets, logits)
+        with MSDA.call_site(self._site()):     # the library picks its encoder-forward kernel per call site
+            if head_major:
+                sampled = MSDA.ms_deform_attn_forward_fused(value, input_spatial_shapes, input_level_start_index,
+                                                            reference_points, offsets.contiguous(), logits.contiguous(),
+                                                            self.n_points, value_head_major=True)
+            elif self._can_fuse(value, reference_points, offsets, logits):
+                sampled = MSDA.ms_deform_attn_forward_fused(value, input_spatial_shapes, input_level_start_index,
+                                                            reference_points, offsets, logits, self.n_points)
+            else:
+                sampled = self._sample_autograd(value, input_spatial_shapes, input_level_start_index, reference_points,
+                                                offsets, logits)
         if residual_norm is not None:
             return self._project_norm(self.output_proj, sampled, residual_norm[0], residual_norm[1])
         return self._project(self.output_proj, sampled)

@@ -23,6 +23,46 @@ R50_LEVELS_TRAIN = ((100, 168), (50, 84), (25, 42), (13, 21))   # padded to 800 
 HEADS, HEAD_DIM, POINTS = 8, 32, 4
 
 
+def pyramid(height, width, strides=(8, 16, 32, 64)):
+    """Feature levels of an image: ceil(size / stride) per level -- the strides-8/16/32 backbone outputs plus the extra
+    stride-2 convolution of the deformable transformer's input projection (ddetrs_dn.py: num_feature_levels = 4)."""
+    return tuple((-(-height // s), -(-width // s)) for s in strides)
+
+
+# Named op-level workloads for BASELINE.json's configs (SURVEY.md 8(d)); `kind` is what make_inputs() takes, `batch` the
+# per-GPU batch of the config, `num_query` the decoder / ReID-head query count (None: the encoder's Lq = S).
+#   configs[1]  R50 COCO det+seg inference, bs 2, 800 x 1333 (d2 ResNet: no padding)
+#   configs[2]  ConvNeXt-L RefCOCO RES inference: COCO images are 4:3, 800 x 1066 padded to /32 -> 800 x 1088
+#   configs[3]  ViT-H YouTube-VIS 5-frame clip: 720p video at MIN_SIZE_TEST 480 (configs/video_joint_r50.yaml:121) -> 480 x 853,
+#               padded to /32 -> 480 x 864; and at the training scale 360 (MIN_SIZE_TRAIN_MULTI's 320-640 range) -> 360 x 640.
+#               The deformable ReID head (ddetrs_vid_dn.py:37-49, deformable_transformer_dino.py:504-527) adds two decoder-layer
+#               calls per frame whose queries are the frame's matched / kept instances (tens, not 900).
+#   configs[4]  R50 Objects365 training, bs 2 per GPU, padded to /32 -> 800 x 1344; the DN decoder (ddetrs_dn.py:558-712) runs
+#               900 matching queries + up to 200 denoising queries = 1100.
+WORKLOADS = {
+    "r50_infer_encoder": dict(kind="encoder", levels=R50_LEVELS_INFER, batch=2, num_query=None, config=1),
+    "r50_infer_decoder": dict(kind="decoder", levels=R50_LEVELS_INFER, batch=2, num_query=900, config=1),
+    "refcoco_encoder": dict(kind="encoder", levels=pyramid(800, 1088), batch=2, num_query=None, config=2),
+    "refcoco_decoder": dict(kind="decoder", levels=pyramid(800, 1088), batch=2, num_query=900, config=2),
+    "ytvis480_clip_encoder": dict(kind="encoder", levels=pyramid(480, 864), batch=5, num_query=None, config=3),
+    "ytvis480_clip_decoder": dict(kind="decoder", levels=pyramid(480, 864), batch=5, num_query=900, config=3),
+    "ytvis360_clip_encoder": dict(kind="encoder", levels=pyramid(360, 640), batch=5, num_query=None, config=3),
+    "ytvis480_clip_reid": dict(kind="decoder", levels=pyramid(480, 864), batch=5, num_query=64, config=3),
+    "r50_train_encoder": dict(kind="encoder", levels=R50_LEVELS_TRAIN, batch=2, num_query=None, config=4),
+    "r50_train_decoder": dict(kind="decoder", levels=R50_LEVELS_TRAIN, batch=2, num_query=1100, config=4),
+}
+
+
+def make_workload(name, flavour="model", seed=0, device="cuda", **kw):
+    """make_inputs() for a named workload; `wide` = the model-like pattern with sigma = 6 px offsets."""
+    w = WORKLOADS[name]
+    if flavour == "wide":
+        kw.setdefault("offset_sigma", 6.0)
+        flavour = "model"
+    return make_inputs(w["kind"], flavour, batch=w["batch"], levels=w["levels"], num_query=w["num_query"], seed=seed,
+                       device=device, **kw)
+
+
 def level_tensors(levels, device):
     shapes = torch.as_tensor(levels, dtype=torch.int64, device=device)
     hw = shapes[:, 0] * shapes[:, 1]
