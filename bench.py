@@ -508,6 +508,12 @@ def main():
             },
         }
         out.update(extras)
+        # the headline is taken on ONE location distribution: say which, how local it is (far fraction reported by the window
+        # kernel) and which kernel the call sites settled on; `flavours` holds the launch time on the other two
+        ff = extras.get("forward_kernels", {}).get("far_fraction", {}) if isinstance(extras.get("forward_kernels"), dict) else {}
+        out["config"]["location_flavour"] = args.flavour
+        out["config"]["far_fraction"] = ff.get(args.flavour)
+        out["config"]["far_fraction_other_flavours"] = {k: v for k, v in ff.items() if k != args.flavour}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.flavour)
         print(json.dumps(out), flush=True)

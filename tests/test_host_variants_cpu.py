@@ -131,3 +131,23 @@ def test_module_on_cpu_matches_the_grid_sample_composition():
     g1, = torch.autograd.grad(out.sum(), q, retain_graph=True)
     g2, = torch.autograd.grad(want.sum(), q)
     assert scaled_err(g1.numpy(), g2.numpy()) < 1e-4
+
+
+def test_host_variants_reject_levels_outside_the_value_tensor():
+    """the host-pointer entry points index plain memory with spatial_shapes / level_start_index; geometry that
+    does not fit spatial_size must be refused (MSDA_ERR_BAD_DIMS), not dereferenced."""
+    import torch
+    from uninext_amd import ext
+    value = torch.randn(1, 20, 2, 4)
+    shapes = torch.tensor([[4, 4], [2, 2]], dtype=torch.int64)
+    loc = torch.rand(1, 3, 2, 2, 2, 2)
+    attn = torch.softmax(torch.randn(1, 3, 2, 4), -1).view(1, 3, 2, 2, 2)
+    ok = ext.ms_deform_attn_forward(value, shapes, torch.tensor([0, 16], dtype=torch.int64), loc, attn, 64)
+    assert ok.shape == (1, 3, 8)
+    for bad_lsi in ([0, 17], [-1, 16], [0, 1 << 40]):
+        with pytest.raises(RuntimeError):
+            ext.ms_deform_attn_forward(value, shapes, torch.tensor(bad_lsi, dtype=torch.int64), loc, attn, 64)
+        with pytest.raises(RuntimeError):
+            ext.ms_deform_attn_backward(value, shapes, torch.tensor(bad_lsi, dtype=torch.int64), loc, attn, torch.randn(1, 3, 8), 64)
+    with pytest.raises(RuntimeError):
+        ext.ms_deform_attn_forward(value, torch.tensor([[4, 4], [0, 2]], dtype=torch.int64), torch.tensor([0, 16], dtype=torch.int64), loc, attn, 64)

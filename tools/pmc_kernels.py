@@ -45,7 +45,8 @@ def main():
     rows = c.execute("select dispatch_id, kernel_name, counter_name, value from counters_collection order by dispatch_id").fetchall()
     per = {}
     for did, name, cn, val in rows:
-        per.setdefault(did, [name, {}])[1][cn] = per[did][1].get(cn, 0.0) + val
+        e = per.setdefault(did, [name, {}])
+        e[1][cn] = e[1].get(cn, 0.0) + val
     agg, seen = {}, {}
     for did in sorted(per):
         name, vals = per[did]

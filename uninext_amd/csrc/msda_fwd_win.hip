@@ -265,6 +265,7 @@ __device__ __forceinline__ void win_body(const float* __restrict__ value, const 
       // round 0 = the level-0 queries of the tile, wave = tile row, quad = tile column (no division)
       live = pq < (int)qb<0>((uint32_t)nx) && wv < (int)qb<0>((uint32_t)(ye - ys));
       const int q = lvS[0] + ((int)qb<0>((uint32_t)ys) + wv) * lvW[0] + (int)qb<0>((uint32_t)xs) + pq;
+      live = live && q < d.Lq;                             // (shapes whose pixel count exceeds num_query: never outside the tensors)
       qidx = (uint32_t)(live ? q : 0);
       pair = mad_u24(qidx, (uint32_t)M, (uint32_t)m);
       fetch(kq);
@@ -559,6 +560,7 @@ __device__ __forceinline__ void win_body(const float* __restrict__ value, const 
         const int Wq = qWS.x, Sq = qWS.y;
         const int yy = (int)(((float)j + 0.5f) * __builtin_amdgcn_rcpf((float)max(ge.z, 1)));
         const uint32_t qn = mad_u24((uint32_t)(ge.y + yy), (uint32_t)Wq, (uint32_t)(Sq + ge.x + j)) - mad_u24((uint32_t)yy, (uint32_t)ge.z, 0u);
+        live = live && qn < (uint32_t)d.Lq;
         qidx = live ? qn : 0u;
         pair = mad_u24(qidx, (uint32_t)M, (uint32_t)m);
         fetch(k);

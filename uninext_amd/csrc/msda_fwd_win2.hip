@@ -313,9 +313,7 @@ msda_fwd_win2(const float* __restrict__ value, const int64_t* __restrict__ shape
         qidx = mad_u24((uint32_t)(qys + yy), (uint32_t)Wq, (uint32_t)(Sq + qxs + j)) - mad_u24((uint32_t)yy, (uint32_t)qnx, 0u);
       }
       // ---- locations and weights of point k on the four levels (the quad reads 32 + 16 contiguous bytes per level) --
-#ifdef MSDA_WIN2_DEBUG_CLAMP
-      if (qidx >= (uint32_t)d.Lq) { live = false; }
-#endif
+      live = live && qidx < (uint32_t)d.Lq;                  // (shapes whose pixel count exceeds num_query: never outside the tensors)
       const uint32_t pair = mul_u24_s(live ? qidx : 0u, (uint32_t)M);   // (query, head 0) pair within the image; the head sits in the base pointers
 #ifdef MSDA_WIN2_DBG_ADDR
       {

@@ -34,8 +34,22 @@ int check(const HostDims& d, bool ptrs_ok) {
   return 0;
 }
 
+// The host pointers are dereferenced at value[(b * S + lsi[l] + pixel) * M * D ...]: levels that do not lie inside
+// [0, spatial_size) would read -- and the backward WRITE -- outside the tensors (the GPU kernels are clamped by their
+// buffer descriptors; plain host memory is not).
+int check_geometry(const HostDims& d, const int64_t* shapes, const int64_t* lsi) {
+  for (int l = 0; l < d.L; ++l) {
+    const int64_t H = shapes[2 * l], W = shapes[2 * l + 1], st = lsi[l];
+    if (H <= 0 || W <= 0 || H > (int64_t)d.S || W > (int64_t)d.S || st < 0 || st + H * W > (int64_t)d.S)
+      return dynmask_set_error(MSDA_ERR_BAD_DIMS, "spatial_shapes / level_start_index do not fit spatial_size");
+  }
+  return 0;
+}
+
 int thread_count(int requested, int64_t items) {
   int n = requested > 0 ? requested : (int)std::thread::hardware_concurrency();
+  // threads are created per call: not more than one per ~256 work units (a 600-row decoder call gets 2-3, not 256)
+  if (requested <= 0) n = (int)std::min<int64_t>(n, std::max<int64_t>(1, items / 256));
   if (n < 1) n = 1;
   if ((int64_t)n > items) n = (int)std::max<int64_t>(items, 1);
   return n;
@@ -81,6 +95,8 @@ template <typename T>
 int forward_host(const T* value, const int64_t* shapes, const int64_t* lsi, const T* loc, const T* attn,
                  const HostDims& d, T* out, int num_threads) {
   if (int rc = check(d, value && shapes && lsi && loc && attn && out)) return rc;
+  if (d.N > 0 && d.Lq > 0)
+    if (int rc = check_geometry(d, shapes, lsi)) return rc;
   if (d.N == 0 || d.Lq == 0) return 0;
   const int64_t rows = (int64_t)d.N * d.Lq;
   const int64_t pix_stride = (int64_t)d.M * d.D;
@@ -122,6 +138,8 @@ template <typename T>
 int backward_host(const T* grad_out, const T* value, const int64_t* shapes, const int64_t* lsi, const T* loc,
                   const T* attn, const HostDims& d, T* grad_value, T* grad_loc, T* grad_attn, int num_threads) {
   if (int rc = check(d, grad_out && value && shapes && lsi && loc && attn && grad_value && grad_loc && grad_attn)) return rc;
+  if (d.N > 0 && d.Lq > 0)
+    if (int rc = check_geometry(d, shapes, lsi)) return rc;
   if (d.N == 0 || d.Lq == 0) return 0;
   const int64_t slices = (int64_t)d.N * d.M;     // a thread owns grad_value[b, :, m, :]
   const int64_t pix_stride = (int64_t)d.M * d.D;
