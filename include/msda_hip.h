@@ -183,8 +183,8 @@ const char* msda_hip_last_kernel(int which);
  * x 4 points).  The LDS-window kernel (msda_fwd_win) is faster than the gather kernel (msda_fwd_lg3) while the samples
  * of a query stay within a few pixels of it and slower when they do not, and only the sampling locations tell.
  *
- * msda_hip_set_call_context(call_site, flags) describes the NEXT forward call made from the calling thread (operator or
- * fused entry point; the context is consumed by that call):
+ * msda_hip_set_call_context(call_site, flags) describes the NEXT forward or backward call made from the calling thread
+ * (operator or fused entry point; the context is consumed by that call):
  *   call_site   0..63: the caller's slot.  The choice is made PER CALL SITE -- the six encoder layers of a model each
  *               pass their own and each converge on their own kernel.  < 0: no automatic choice (gather kernel).
  *   flags       MSDA_CTX_GEOMETRY_CHECKED  the caller vouches that sum_l H_l * W_l == spatial_size and that
@@ -204,6 +204,11 @@ const char* msda_hip_last_kernel(int which);
  * gather kernel with every 64th call sent through the window kernel to refresh the report.  Two runs of the same call sequence are bitwise equal; the two kernels differ from each
  * other in fp32 summation order only.  Under a stream capture (events cannot be waited for) and with
  * MSDA_HIP_FWD_ADAPTIVE=0 in the environment variant 0 takes the gather kernel.
+ *
+ * Backward (variant 0, fp32, encoder shape): msda_bwd_win -- value and gradient windows in LDS -- when the call carries a
+ * context (geometry vouched for, not deterministic) and the FORWARD calls of that call site have last reported a far
+ * fraction <= 0.05; msda_bwd_tiled otherwise (no context, no forward yet, samples not near).  A backward call launches
+ * no report and waits for nothing: its choice follows the call sequence of the site's forward calls.
  *
  * msda_hip_forward_locality: number of reports consumed so far on the call site used last on the current device (it
  * waits for the launches made so far on that site) and, in *far_fraction (may be NULL), the far fraction of the latest.

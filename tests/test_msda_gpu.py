@@ -134,9 +134,9 @@ def test_quarter_scale_r50_vs_oracle(kind, flavour, dev, api):
     assert max_abs(_np(out), ref) < 1e-4
     go = torch.randn(out.shape, generator=torch.Generator().manual_seed(5)).to(dev)
     ogv, ogl, oga = msda_oracle.backward(go, x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
-    for variant in ("msda_bwd_generic", "msda_bwd_lanegroup", "msda_bwd_tiled"):
-        if variant == "msda_bwd_tiled" and kind != "encoder":
-            continue   # the tiled backward needs Lq == S; other calls fall back to the generic kernel
+    for variant in ("msda_bwd_generic", "msda_bwd_lanegroup", "msda_bwd_tiled", "msda_bwd_win"):
+        if variant in ("msda_bwd_tiled", "msda_bwd_win") and kind != "encoder":
+            continue   # the tiled / window backward need Lq == S; other calls fall back to the generic kernel
         lib.set_variant("backward", variant)
         try:
             gv, gl, ga = MSDA.ms_deform_attn_backward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], go, 64)
@@ -364,7 +364,7 @@ def test_full_size_encoder_backward(levels, variant, dev, api):
         gv, gl, ga = MSDA.ms_deform_attn_backward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], go, 64)
     finally:
         lib.set_variant("backward", "auto")
-    assert lib.last_kernel("backward") == ("msda_bwd_tiled" if variant == "auto" else variant)
+    assert lib.last_kernel("backward") in (("msda_bwd_tiled", "msda_bwd_win") if variant == "auto" else (variant,))
     # per-query gradients: oracle on a query subset
     idx = torch.cat([torch.arange(0, 200), torch.arange(S - 200, S),
                      torch.randint(0, S, (400,), generator=torch.Generator().manual_seed(2))]).to(dev)

@@ -54,6 +54,17 @@ def _inputs(flavour, levels, seed, dev):
     return workloads.make_inputs("encoder", batch=2, levels=levels, seed=seed, device=dev, **kw)
 
 
+ENCODER_BWD = ("msda_bwd_tiled", "msda_bwd_win")     # what variant "auto" may take on an encoder-shaped fp32 call
+
+
+def _bwd(MSDA, lib, x, go, variant):
+    lib.set_variant("backward", variant)
+    try:
+        return MSDA.ms_deform_attn_backward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], go, 64)
+    finally:
+        lib.set_variant("backward", "auto")
+
+
 def _fwd(MSDA, lib, x, variant):
     lib.set_variant("forward", variant)
     try:
@@ -213,8 +224,9 @@ def test_window_forward_falls_back_outside_its_geometry(dev, api):
     assert lib.last_kernel("forward") == "msda_fwd_lanegroup"
 
 
+@pytest.mark.parametrize("kernel", ENCODER_BWD)
 @pytest.mark.parametrize("flavour", ["model", "uniform"])
-def test_full_size_backward_every_query(flavour, dev, api):
+def test_full_size_backward_every_query(flavour, kernel, dev, api):
     from oracle import msda_oracle
     from uninext_amd import workloads
     MSDA, lib = api
@@ -222,8 +234,8 @@ def test_full_size_backward_every_query(flavour, dev, api):
     x = _inputs(flavour, levels, 19, dev)
     S = x["value"].shape[1]
     go = torch.randn(2, S, 256, generator=torch.Generator().manual_seed(20)).to(dev)
-    gv, gl, ga = MSDA.ms_deform_attn_backward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], go, 64)
-    assert lib.last_kernel("backward") == "msda_bwd_tiled"
+    gv, gl, ga = _bwd(MSDA, lib, x, go, kernel)
+    assert lib.last_kernel("backward") == kernel
     ogv, ogl, oga = msda_oracle.backward(go, x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
     # grad_value and grad_attn are continuous in the location, so the float64 run of the oracle on the same float32
     # inputs is the yardstick for them (it also shows what float32 itself costs: the float32 oracle's own distance
@@ -234,8 +246,8 @@ def test_full_size_backward_every_query(flavour, dev, api):
     print("float32 oracle vs float64: grad_value %.2e grad_attn %.2e" % (float(np.abs(ogv - tgv).max()), float(np.abs(oga - tga).max())))
     d_gl = np.abs(gl.cpu().numpy().astype(np.float64) - ogl)          # [N, Lq, M, L, P, 2]
     e_gl = [float(d_gl[:, :, :, l].max()) for l in range(4)]
-    print("backward %-8s grad_value %.2e (max |ref| %.1f)  grad_attn %.2e (max |ref| %.1f)  grad_loc per level %s (bounds %s)" % (
-        flavour, e_gv, float(np.abs(ogv).max()), e_ga, float(np.abs(oga).max()), ["%.1e" % e for e in e_gl],
+    print("%s %-8s grad_value %.2e (max |ref| %.1f)  grad_attn %.2e (max |ref| %.1f)  grad_loc per level %s (bounds %s)" % (
+        kernel, flavour, e_gv, float(np.abs(ogv).max()), e_ga, float(np.abs(oga).max()), ["%.1e" % e for e in e_gl],
         ["%.1e" % (1e-4 * max(h, w)) for h, w in levels]))
     o_ga = float(np.abs(oga - tga).max())
     assert e_gv < 1e-4, e_gv
@@ -244,8 +256,97 @@ def test_full_size_backward_every_query(flavour, dev, api):
         assert e_gl[l] < 1e-4 * max(h, w), (l, e_gl[l])
 
 
-def test_tiled_backward_fixed_point_bound_under_high_dynamic_range(dev, api):
-    """include/msda_hip.h, numerics of grad_value: msda_bwd_tiled rounds every add to <= 2^-22 of the tile's largest
+@pytest.mark.parametrize("flavour", ["model", "wide", "uniform"])
+@pytest.mark.parametrize("levels", ODD_PYRAMIDS)
+def test_window_backward_on_odd_pyramids(levels, flavour, dev, api):
+    """msda_bwd_win enumerates its queries from the level shapes like the window forward; every query against the oracle
+    on pyramids whose tiles are ragged, thin, over-full (> 256 pairs: the float-atomic path) or of equal resolution."""
+    from oracle import msda_oracle
+    MSDA, lib = api
+    x = _inputs(flavour, levels, 61, dev)
+    S = x["value"].shape[1]
+    go = torch.randn(2, S, 256, generator=torch.Generator().manual_seed(62)).to(dev)
+    gv, gl, ga = _bwd(MSDA, lib, x, go, "msda_bwd_win")
+    assert lib.last_kernel("backward") == ("msda_bwd_win" if S >= 1024 else "msda_bwd_generic")
+    ogv, ogl, oga = msda_oracle.backward(go, x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
+    tgv, _, tga = msda_oracle.backward(go.double(), x["value"].double(), x["shapes"], x["lsi"], x["loc"].double(), x["attn"].double())
+    e_gv = float(np.abs(gv.cpu().numpy().astype(np.float64) - tgv).max())
+    e_ga = float(np.abs(ga.cpu().numpy().astype(np.float64) - tga).max())
+    o_gv, o_ga = float(np.abs(ogv - tgv).max()), float(np.abs(oga - tga).max())
+    assert e_gv < max(1e-4, 2.0 * o_gv), (e_gv, o_gv)
+    assert e_ga < max(1e-4, 2.0 * o_ga), (e_ga, o_ga)
+    d_gl = np.abs(gl.cpu().numpy().astype(np.float64) - ogl)
+    for l, (h, w) in enumerate(levels):
+        assert float(d_gl[:, :, :, l].max()) < 1e-4 * max(h, w), (l, float(d_gl[:, :, :, l].max()))
+
+
+def test_backward_choice_follows_the_forward_reports_of_its_call_site(dev, api):
+    """include/msda_hip.h: variant 0 backward on the encoder shape takes msda_bwd_win when the forward calls of the SAME call
+    site have reported near samples, msda_bwd_tiled otherwise -- no forward yet on the site, far samples, no context
+    (deterministic mode), or another site's reports."""
+    from uninext_amd import ext, workloads
+    MSDA, lib = api
+    near = _inputs("model", workloads.R50_LEVELS_INFER, 71, dev)
+    far = _inputs("uniform", workloads.R50_LEVELS_INFER, 72, dev)
+    S = near["value"].shape[1]
+    go = torch.randn(2, S, 256, generator=torch.Generator().manual_seed(73)).to(dev)
+
+    def fwd(x):
+        return MSDA.ms_deform_attn_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], 64)
+
+    def bwd(x):
+        out = MSDA.ms_deform_attn_backward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], go, 64)
+        return lib.last_kernel("backward"), out
+
+    with ext.call_site(41):
+        assert bwd(near)[0] == "msda_bwd_tiled"            # nothing reported on this site yet
+        for _ in range(4):
+            fwd(near)
+        k_near, g_near = bwd(near)
+        assert k_near == "msda_bwd_win"
+        for _ in range(12):                                  # (a site in window mode reports every 8th launch, consumed 2 calls later)
+            fwd(far)
+        assert bwd(far)[0] == "msda_bwd_tiled"
+    with ext.call_site(42):
+        assert bwd(near)[0] == "msda_bwd_tiled"            # site 41's reports are not site 42's
+    with ext.call_site(41):
+        for _ in range(4):                                   # (a site in gather mode sends every 64th call through the window kernel:
+            fwd(near)                                        # it stays there; site 44 has seen near samples only)
+        assert bwd(near)[0] == "msda_bwd_tiled"
+    with ext.call_site(44):
+        for _ in range(4):
+            fwd(near)
+        torch.use_deterministic_algorithms(True)
+        try:
+            assert bwd(near)[0] == "msda_bwd_tiled"
+        finally:
+            torch.use_deterministic_algorithms(False)
+        k2, g2 = bwd(near)
+        assert k2 == "msda_bwd_win"
+    # the two kernels agree with each other far inside the oracle bounds
+    ref = _bwd(MSDA, lib, near, go, "msda_bwd_tiled")
+    for a, b in zip(g_near, ref):
+        assert float((a - b).abs().max()) < 1e-4 * 168
+
+
+def test_autograd_backward_runs_at_the_call_site_of_its_forward(dev, api):
+    """MSDeformAttnFunction records the call site in forward and re-enters it in backward (the autograd thread)."""
+    from uninext_amd import ext, workloads
+    from uninext_amd.functions import MSDeformAttnFunction
+    MSDA, lib = api
+    x = _inputs("model", workloads.R50_LEVELS_INFER, 75, dev)
+    value, loc, attn = (x[k].clone().requires_grad_(True) for k in ("value", "loc", "attn"))
+    with ext.call_site(43):
+        for _ in range(4):
+            out = MSDeformAttnFunction.apply(value, x["shapes"], x["lsi"], loc, attn, 64)
+    out.sum().backward()                                     # outside of the block
+    assert lib.last_kernel("backward") == "msda_bwd_win"
+    assert value.grad is not None and loc.grad is not None and attn.grad is not None
+
+
+@pytest.mark.parametrize("kernel", ENCODER_BWD)
+def test_tiled_backward_fixed_point_bound_under_high_dynamic_range(kernel, dev, api):
+    """include/msda_hip.h, numerics of grad_value: msda_bwd_tiled and msda_bwd_win round every add to <= 2^-22 of the tile's largest
     upstream gradient.  Upstream gradients with 8 decades of dynamic range from query to query: the error stays
     within the documented worst case relative to the GLOBAL maximum everywhere, pixels fed only by small gradients
     are resolved to the documented absolute step (not to fp32 relative precision), and the pinned float-atomic kernel
@@ -260,11 +361,11 @@ def test_tiled_backward_fixed_point_bound_under_high_dynamic_range(dev, api):
     go = (torch.randn(2, S, 256, generator=g) * mag).to(dev)
     gmax = float(go.abs().max())
     tgv, _, _ = msda_oracle.backward(go.double(), x["value"].double(), x["shapes"], x["lsi"], x["loc"].double(), x["attn"].double())
-    gv, _, _ = MSDA.ms_deform_attn_backward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], go, 64)
-    assert lib.last_kernel("backward") == "msda_bwd_tiled"
+    gv, _, _ = _bwd(MSDA, lib, x, go, kernel)
+    assert lib.last_kernel("backward") == kernel
     err = np.abs(gv.cpu().numpy().astype(np.float64) - tgv)
     step = gmax * 2.0 ** -22                                                 # the largest rounding step of any tile
-    print("tiled: max |err| %.3e = %.1f steps of 2^-22 max|grad_out| (%.3e)" % (float(err.max()), float(err.max()) / step, step))
+    print("%s: max |err| %.3e = %.1f steps of 2^-22 max|grad_out| (%.3e)" % (kernel, float(err.max()), float(err.max()) / step, step))
     assert float(err.max()) < 64.0 * step                                     # far inside the 1300-add worst case
     lib.set_variant("backward", "msda_bwd_generic")
     try:
@@ -349,7 +450,7 @@ def test_encoder_shaped_reference_fixture_forward(variant, dev, api):
     assert float(np.abs(out.cpu().numpy().reshape(g["out"].shape) - g["out"]).max()) < 1e-4
 
 
-@pytest.mark.parametrize("variant", ["auto", "msda_bwd_tiled", "msda_bwd_generic"])
+@pytest.mark.parametrize("variant", ["auto", "msda_bwd_tiled", "msda_bwd_win", "msda_bwd_generic"])
 def test_encoder_shaped_reference_fixture_backward(variant, dev, api):
     """The backward kernels on the same fixture (autograd through the reference's function in float64)."""
     from golden_util import load_golden
@@ -361,7 +462,7 @@ def test_encoder_shaped_reference_fixture_backward(variant, dev, api):
         gv, gl, ga = MSDA.ms_deform_attn_backward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], x["grad_out"], 64)
     finally:
         lib.set_variant("backward", "auto")
-    assert lib.last_kernel("backward") == ("msda_bwd_tiled" if variant == "auto" else variant)
+    assert lib.last_kernel("backward") in (ENCODER_BWD if variant == "auto" else (variant,))
     assert float(np.abs(gv.cpu().numpy() - g["grad_value"]).max()) < 1e-4
     assert float(np.abs(ga.cpu().numpy() - g["grad_attn"]).max()) < 2e-4       # float32 evaluation of the bilinear form
     d = np.abs(gl.cpu().numpy() - g["grad_loc"])                                # [1, Lq, M, L, P, 2]
@@ -388,15 +489,16 @@ def test_encoder_kernels_on_other_batch_sizes_and_head_counts(heads, batch, dev,
         assert float(np.abs(out.cpu().numpy().astype(np.float64) - ref).max()) < 1e-4, kernel
     S = x["value"].shape[1]
     go = torch.randn(batch, S, heads * 32, generator=torch.Generator().manual_seed(7)).to(dev)
-    gv, gl, ga = MSDA.ms_deform_attn_backward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], go, 64)
-    assert lib.last_kernel("backward") == "msda_bwd_tiled"
     tgv, _, tga = msda_oracle.backward(go.double(), x["value"].double(), x["shapes"], x["lsi"], x["loc"].double(), x["attn"].double())
     ogv, ogl, oga = msda_oracle.backward(go, x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
-    assert float(np.abs(gv.cpu().numpy().astype(np.float64) - tgv).max()) < 1e-4
-    assert float(np.abs(ga.cpu().numpy().astype(np.float64) - tga).max()) < max(1e-4, 2.0 * float(np.abs(oga - tga).max()))
-    d_gl = np.abs(gl.cpu().numpy().astype(np.float64) - ogl)
-    for l, (h, w) in enumerate(levels):
-        assert float(d_gl[:, :, :, l].max()) < 1e-4 * max(h, w)
+    for kernel in ENCODER_BWD:
+        gv, gl, ga = _bwd(MSDA, lib, x, go, kernel)
+        assert lib.last_kernel("backward") == kernel
+        assert float(np.abs(gv.cpu().numpy().astype(np.float64) - tgv).max()) < 1e-4, kernel
+        assert float(np.abs(ga.cpu().numpy().astype(np.float64) - tga).max()) < max(1e-4, 2.0 * float(np.abs(oga - tga).max())), kernel
+        d_gl = np.abs(gl.cpu().numpy().astype(np.float64) - ogl)
+        for l, (h, w) in enumerate(levels):
+            assert float(d_gl[:, :, :, l].max()) < 1e-4 * max(h, w), kernel
 
 
 @pytest.mark.parametrize("heads", [1, 3, 5, 7])

@@ -391,7 +391,17 @@ int launch_backward<float>(int variant, const float* grad_out, const float* valu
   // encoder call), msda_bwd_lanegroup 8 lines of 8 scattered dwords (8.2 ms), msda_bwd_tiled combines the adds
   // in LDS first (0.48 ms).  `auto`: tiled for encoder-style calls, generic otherwise.
   const bool tl = tiled_backward_ok(d);
-  if (variant == kAuto) variant = (tl && d.S >= 1024) ? kTiled : kGeneric;
+  constexpr int kBwdWin = 4;            // backward variant 4: msda_bwd_win (value + gradient windows in LDS)
+  if (variant == kAuto) {
+    // encoder-style calls: msda_bwd_win where the forward calls of the call site have reported near samples
+    // (win_backward_auto, msda_fwd_win.hip), msda_bwd_tiled otherwise; generic for everything else
+    variant = (tl && d.S >= 1024) ? (win_backward_auto(d) ? kBwdWin : kTiled) : kGeneric;
+  }
+  drop_call_context();
+  if (variant == kBwdWin && win_backward_ok(d)) {
+    *kernel_name = "msda_bwd_win";
+    return launch_backward_win(grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, stream);
+  }
   if (variant >= kTiled && !tl) variant = kGeneric;
   if (variant >= kTiled) {
     *kernel_name = "msda_bwd_tiled";
@@ -424,6 +434,7 @@ int launch_backward<double>(int /*variant*/, const double* grad_out, const doubl
                             const int64_t* lsi, const double* loc, const double* attn, const Dims& d,
                             double* grad_value, double* grad_loc, double* grad_attn, hipStream_t stream,
                             const char** kernel_name) {
+  drop_call_context();
   *kernel_name = "msda_bwd_generic";
   return launch_generic<double>(grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, stream);
 }

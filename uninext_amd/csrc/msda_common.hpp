@@ -114,9 +114,16 @@ int launch_backward_tiled(const float* grad_out, const float* value, const int64
                           const float* loc, const float* attn, const Dims& d, float* grad_value, float* grad_loc,
                           float* grad_attn, hipStream_t stream);
 
+// msda_bwd_win.hip: encoder backward with value AND gradient windows in LDS (fp32, D = 32, L = P = 4, Lq == S).
+bool win_backward_ok(const Dims& d);
+int launch_backward_win(const float* grad_out, const float* value, const int64_t* shapes, const int64_t* lsi,
+                        const float* loc, const float* attn, const Dims& d, float* grad_value, float* grad_loc,
+                        float* grad_attn, hipStream_t stream);
+
 // msda_fwd_win.hip: encoder forward with LDS windows on all four levels (fp32, D = 32, L = P = 4, Lq == S).
 bool win_forward_ok(const Dims& d);
 bool win_forward_auto(const Dims& d, hipStream_t stream);   // auto dispatch: take the window kernel for this call? (consumes the call context)
+bool win_backward_auto(const Dims& d);                       // backward of a site whose forward calls reported near samples? (consumes the context)
 void set_call_context(int slot, unsigned flags);            // include/msda_hip.h: msda_hip_set_call_context
 void drop_call_context();
 int launch_forward_win_fused(const float* value, int head_major, const int64_t* shapes, const int64_t* lsi,

@@ -816,6 +816,29 @@ int forward_locality(double* far_fraction) {
 }
 
 // auto dispatch of the encoder shape: window kernel or msda_fwd_lg3?  Consumes the thread's call context.
+// Backward of an encoder-shaped call made with a call context: msda_bwd_win (value and gradient windows in LDS) when the
+// FORWARD calls of the same site have reported that the samples stay near their tiles, msda_bwd_tiled otherwise.  Nothing
+// is launched or waited for here -- the slot's state only changes inside forward calls, so the choice is a function of
+// the call sequence like the forward's.  Measured (profiles/r03_backward_window.txt): far 0.02 -> 336 us against 360,
+// far 0.41 -> 1128 against 924; the lines cross near 0.06.
+constexpr double kFarFractionMaxBwd = 0.05;
+bool win_backward_auto(const Dims& d) {
+  static const int mode_env = [] { const char* e = std::getenv("MSDA_HIP_FWD_ADAPTIVE"); return e ? std::atoi(e) : 1; }();
+  const CallContext ctx = t_ctx;
+  t_ctx = CallContext();
+  t_pending = Pending();
+  if (mode_env == 0 || !ctx.set || ctx.slot < 0 || ctx.slot >= kSites || !(ctx.flags & 1u) || (ctx.flags & 2u) ||
+      !win_backward_ok(d))
+    return false;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices ||
+      g_loc_ready[dev].load(std::memory_order_acquire) != 1)
+    return false;                                 // no forward call has dispatched automatically on this device yet
+  Slot& sl = g_loc[dev]->slots[ctx.slot];
+  std::lock_guard<std::mutex> lock(sl.mu);
+  return sl.mode == 1 && sl.far <= kFarFractionMaxBwd;
+}
+
 bool win_forward_auto(const Dims& d, hipStream_t stream) {
   static const int mode_env = [] { const char* e = std::getenv("MSDA_HIP_FWD_ADAPTIVE"); return e ? std::atoi(e) : 1; }();
   const CallContext ctx = t_ctx;

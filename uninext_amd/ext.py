@@ -45,6 +45,12 @@ def call_site(site):
         _site.value = prev
 
 
+def current_call_site():
+    """The call site of the enclosing call_site() block (0 outside of one) -- autograd functions record it in forward and
+    re-enter it in backward, which runs on another thread."""
+    return int(getattr(_site, "value", 0))
+
+
 def _geometry_checked(spatial_shapes, level_start_index, spatial_size):
     """sum_l H_l * W_l == spatial_size and level_start_index == the prefix sums -- the precondition of the window kernels,
     which the reference operator itself does not require.  A device -> host copy, done once per shapes TENSOR OBJECT (weak
@@ -64,7 +70,7 @@ def _geometry_checked(spatial_shapes, level_start_index, spatial_size):
 
 
 def _set_call_context(lib, value_dtype, spatial_shapes, level_start_index, S, M_D, L, Lq, P):
-    """Describe the coming forward call to the library.  Only encoder-shaped fp32 calls have a choice to make; for
+    """Describe the coming forward or backward call to the library.  Only encoder-shaped fp32 calls have a choice to make; for
     everything else no context is set (and nothing is copied to the host)."""
     if value_dtype != torch.float32 or Lq != S or S < 1024 or L != 4 or P != 4 or M_D != 32:
         return
@@ -188,6 +194,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     grad_attn = torch.empty_like(attn_weight)
     with torch.cuda.device(value.device):
         stream = torch.cuda.current_stream().cuda_stream
+        _set_call_context(lib, value.dtype, spatial_shapes, level_start_index, S, D, L, Lq, P)
         rc = getattr(lib, "msda_hip_backward_" + suf)(
             grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
             sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P, grad_value.data_ptr(),

@@ -21,6 +21,7 @@ class MSDeformAttnFunction(Function):
     def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights,
                 im2col_step):
         ctx.im2col_step = im2col_step
+        ctx.call_site = MSDA.current_call_site()        # backward runs on the autograd thread: same site there
         output = MSDA.ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index,
                                              sampling_locations, attention_weights, ctx.im2col_step)
         ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
@@ -32,6 +33,7 @@ class MSDeformAttnFunction(Function):
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, grad_output):
         value, shapes, level_start, locations, weights = ctx.saved_tensors
-        grad_value, grad_loc, grad_attn = MSDA.ms_deform_attn_backward(
-            value, shapes, level_start, locations, weights, grad_output.contiguous(), ctx.im2col_step)
+        with MSDA.call_site(ctx.call_site):
+            grad_value, grad_loc, grad_attn = MSDA.ms_deform_attn_backward(
+                value, shapes, level_start, locations, weights, grad_output.contiguous(), ctx.im2col_step)
         return grad_value, None, None, grad_loc, grad_attn, None
