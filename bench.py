@@ -248,11 +248,17 @@ def measure_forward_kernels(enc, reps=12):
     return out
 
 
-def backward_call(x, go, gv, gl, ga):
+BWD_SITE = 30   # call site of measure_backward's encoder calls (forward and backward, as a module's are)
+
+
+def backward_call(x, go, gv, gl, ga, site=-1):
     """The C-ABI backward on pre-allocated outputs (uninext_amd.ext allocates them per call; here the launch alone
-    is what the events bracket)."""
+    is what the events bracket).  site >= 0: the call carries that call site's context, like the backward of a module
+    (include/msda_hip.h: the encoder backward kernel follows the forward reports of its site)."""
     import ctypes
     lib = _lib.load()
+    if site >= 0:
+        lib.msda_hip_set_call_context(site, 1)        # geometry vouched for: checked by the forward calls of the site
     N, S, M, D = x["value"].shape
     Lq, L, P = x["loc"].shape[1], x["loc"].shape[3], x["loc"].shape[4]
     rc = lib.msda_hip_backward_f32(go.data_ptr(), x["value"].data_ptr(), x["shapes"].data_ptr(), x["lsi"].data_ptr(),
@@ -270,8 +276,13 @@ def measure_backward(enc, dec, reps=10):
             g = torch.Generator().manual_seed(900 + i)
             go = torch.randn(x["value"].shape[0], x["loc"].shape[1], 256, generator=g).cuda()
             sets.append((x, go, torch.zeros_like(x["value"]), torch.empty_like(x["loc"]), torch.empty_like(x["attn"])))
+        site = BWD_SITE if kind == "encoder" else -1
+        if site >= 0:
+            for _ in range(4):                          # a training step runs the forward of a site before its backward
+                for s in sets:
+                    call(s[0], site)
         for s in sets:
-            backward_call(*s)
+            backward_call(*s, site=site)
         k = [0]
 
         def pre():
@@ -279,7 +290,7 @@ def measure_backward(enc, dec, reps=10):
             sets[k[0] % len(sets)][2].zero_()
 
         def one():
-            backward_call(*sets[k[0] % len(sets)])
+            backward_call(*sets[k[0] % len(sets)], site=site)
         us = time_events(one, reps, pre)
         x = xs[0]
         N, S = x["value"].shape[:2]
@@ -290,7 +301,8 @@ def measure_backward(enc, dec, reps=10):
         out[kind] = {"kernel": kern, "launch_us": us, "algorithmic_bytes": alg, "achieved": ach, "unit": "GB/s",
                      "frac": ach / HBM_PEAK_GBS, "traffic": committed_traffic(kern, "backward_" + kind),
                      "shape": "N=%d S=%d Lq=%d" % (N, S, Lq),
-                     "note": "launch only; the grad_value memset (N*S*1024 B) is outside the events"}
+                     "note": "launch only; the grad_value memset (N*S*1024 B) is outside the events"
+                             + ("; the calls carry the context of a call site whose forward calls ran first, as a module's backward does" if site >= 0 else "")}
         del sets
     return out
 
@@ -307,9 +319,10 @@ def train_step_fn(enc, dec):
 
     def step():
         outs = []
-        for v, sh, lsi, loc, attn, go in sets:
+        for i, (v, sh, lsi, loc, attn, go) in enumerate(sets):
             v.grad = loc.grad = attn.grad = None
-            outs.append(MSDeformAttnFunction.apply(v, sh, lsi, loc, attn, 64))
+            with MSDA.call_site(1 + i if i < len(enc) else 0):   # the encoder layers' modules pass their own sites
+                outs.append(MSDeformAttnFunction.apply(v, sh, lsi, loc, attn, 64))
         for o, s in zip(reversed(outs), reversed(sets)):
             o.backward(s[5])
     return step
@@ -317,7 +330,8 @@ def train_step_fn(enc, dec):
 
 def measure_train_step(enc, dec, world, reps=5):
     step = train_step_fn(enc, dec)
-    step()
+    for _ in range(4):                                  # (the call sites' first locality reports are consumed two calls later)
+        step()
     barrier(world)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -330,7 +344,7 @@ def measure_train_step(enc, dec, world, reps=5):
             "workload": "BASELINE configs[4] per-GPU share at the training shapes (bs 2, 800x1344: S=%d; decoder Lq=%d): "
                         "6 encoder + 6 decoder MSDeformAttn forward AND backward calls through MSDeformAttnFunction "
                         "(autograd, incl. output allocation + memsets)" % (enc[0]["value"].shape[1], dec[0]["loc"].shape[1]),
-            "kernels": {"forward": _lib.last_kernel("forward"), "backward_last": _lib.last_kernel("backward")}}
+            "kernels": {"forward_last": _lib.last_kernel("forward"), "backward_last": _lib.last_kernel("backward")}}
 
 
 def measure_ddp(enc, dec, world, reps=5):

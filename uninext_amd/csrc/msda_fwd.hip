@@ -869,8 +869,12 @@ msda_fwd_lgp(const float* __restrict__ value, const int64_t* __restrict__ shapes
     {
       uint32_t vl = v_loc;
       asm volatile("" : "+v"(vl));
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc), rout, vl + (lane_off >> 1),
-                                             (uint32_t)chunk * chunk_bytes, 2 /* nt */);
+      // (the chunk's offset goes into the per-lane offset, the scalar offset stays the immediate 0: behind a
+      // buffer_store_dwordx4 with an SGPR offset the compiler's hazard recogniser lets a VALU instruction overwrite the data
+      // registers in the very next slot, and on gfx950 that store then writes the new value in some lanes --
+      // msda_fwd_win3.hip, found the hard way; nothing overwrote `acc` that early here, but nothing guaranteed it either)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc), rout,
+                                             vl + (lane_off >> 1) + (uint32_t)chunk * chunk_bytes, 0, 2 /* nt */);
     }
     wave_sync();   // the next chunk rewrites the records
   }
@@ -948,6 +952,11 @@ int launch_forward<float>(int variant, const float* value, const int64_t* shapes
   // win_forward_auto follows the locality the window kernel itself reported for the latest launches
   if (variant == kAuto) variant = win_forward_auto(d, stream) ? kWin : (lg3_ok(d) ? kLaneGroupL3 : (lg ? kLaneGroup : kGeneric));
   else drop_call_context();
+  if (variant == kWin3 && !win3_forward_ok(d)) variant = lg3_ok(d) ? kLaneGroupL3 : kLaneGroup;
+  if (variant == kWin3) {
+    *kernel_name = "msda_fwd_win3";
+    return launch_forward_win3(value, shapes, lsi, loc, attn, d, out, stream);
+  }
   if (variant == kWin2 && !win2_forward_ok(d)) variant = lg3_ok(d) ? kLaneGroupL3 : kLaneGroup;
   if (variant == kWin2) {
     *kernel_name = "msda_fwd_win2";
