@@ -299,7 +299,7 @@ def measure_backward(enc, dec, reps=10):
         kern = _lib.last_kernel("backward")
         ach = alg / us / 1e3
         out[kind] = {"kernel": kern, "launch_us": us, "algorithmic_bytes": alg, "achieved": ach, "unit": "GB/s",
-                     "frac": ach / HBM_PEAK_GBS, "traffic": committed_traffic(kern, "backward_" + kind),
+                     "frac": ach / HBM_PEAK_GBS, "traffic": committed_traffic(kern, "backward_" + kind) or committed_traffic(kern, "backward_" + kind + "_win"),
                      "shape": "N=%d S=%d Lq=%d" % (N, S, Lq),
                      "note": "launch only; the grad_value memset (N*S*1024 B) is outside the events"
                              + ("; the calls carry the context of a call site whose forward calls ran first, as a module's backward does" if site >= 0 else "")}

@@ -8,7 +8,9 @@ doubled (gfx950 tallies the 128-byte read requests of wide loads as 64 B), per l
 Runs on the GPU box (from the repository root; rocprofv3 output goes to gpurun_out/traffic_prof).  The parent
 starts `rocprofv3 ... -- python tools/measure_traffic.py --child` once per counter set; the child launches, in this
 order and separated by a marker kernel, `reps` encoder forward calls (variant 0: the window kernel on these inputs), `reps` with the gather
-kernel pinned, `reps` encoder backward calls and `reps` decoder backward calls (BASELINE configs[1] / configs[4] shapes, model-like locations, rotating input sets).
+kernel pinned, `reps` encoder backward calls without a call context (msda_bwd_tiled), `reps` with the context of a call site whose forward calls
+reported near samples (msda_bwd_win) and `reps` decoder backward calls (forward: BASELINE configs[1] shapes; backward: configs[4] training
+shapes; model-like locations, rotating input sets).
 The parent splits the dispatch-ordered counter rows into one run of msda:: kernels per call and writes
 
     {"source_hash": <bench.kernel_source_hash()>, "git": <HEAD>, "entries": {"forward_encoder": {"kernel": ...,
@@ -25,7 +27,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-PHASES = ("forward_encoder", "forward_encoder_lg3", "backward_encoder", "backward_decoder")
+PHASES = ("forward_encoder", "forward_encoder_lg3", "backward_encoder", "backward_encoder_win", "backward_decoder")
 SQ_COUNTERS = ["SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS",
                "SQ_INSTS_VALU", "SQ_INSTS_VMEM_RD", "SQ_LDS_BANK_CONFLICT"]
 
@@ -37,11 +39,13 @@ def child(reps):
     _lib.load()
     marker = torch.zeros(64, device="cuda")
     enc = [workloads.make_inputs("encoder", "model", batch=2, seed=300 + i) for i in range(3)]
-    dec = [workloads.make_inputs("decoder", "model", batch=2, seed=350 + i) for i in range(3)]
+    # the backward phases run on the TRAINING shapes (800 x 1344: S = 22323, decoder Lq = 1100), like bench.py's backward legs
+    enc_t = [workloads.make_workload("r50_train_encoder", "model", seed=320 + i) for i in range(3)]
+    dec_t = [workloads.make_workload("r50_train_decoder", "model", seed=350 + i) for i in range(3)]
     names = {}
     # one untimed call of each kind first (dynamic-LDS opt-in, lazy module load) -- also separated by markers
-    for phase in range(4):
-        xs = enc if phase < 3 else dec
+    for phase in range(len(PHASES)):
+        xs = enc if phase < 2 else enc_t if phase < 4 else dec_t
         bufs = []
         for i, x in enumerate(xs):
             g = torch.Generator().manual_seed(400 + i)
@@ -56,7 +60,11 @@ def child(reps):
                 bench.call(x)
                 _lib.set_variant("forward", "auto")
             else:
-                bench.backward_call(x, *b)
+                if phase == 3 and r == 0:   # the forward calls of call site 1 (inside the dropped warm-up call's run of
+                    for xx in xs:           # kernels): what lets this phase's backward calls take msda_bwd_win
+                        for _ in range(4):
+                            bench.call(xx, 1)
+                bench.backward_call(x, *b, site=1 if phase == 3 else -1)
             marker.add_(1.0)
         names[PHASES[phase]] = _lib.last_kernel("forward" if phase < 2 else "backward")
         del bufs
@@ -137,10 +145,12 @@ def main():
     names, fetch = profile(["FETCH_SIZE"], args.reps, args.workdir, "fetch")
     _, write = profile(["WRITE_SIZE"], args.reps, args.workdir, "write")
     S = sum(h * w for h, w in workloads.R50_LEVELS_INFER)
+    St = sum(h * w for h, w in workloads.R50_LEVELS_TRAIN)
     alg = {"forward_encoder": workloads.algorithmic_bytes_forward(2, S, S),
            "forward_encoder_lg3": workloads.algorithmic_bytes_forward(2, S, S),
-           "backward_encoder": workloads.algorithmic_bytes_backward(2, S, S),
-           "backward_decoder": workloads.algorithmic_bytes_backward(2, S, 900)}
+           "backward_encoder": workloads.algorithmic_bytes_backward(2, St, St),
+           "backward_encoder_win": workloads.algorithmic_bytes_backward(2, St, St),
+           "backward_decoder": workloads.algorithmic_bytes_backward(2, St, 1100)}
     try:
         git = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
     except OSError:
