@@ -57,7 +57,7 @@ def test_abi_version_and_variant_table(lib):
     assert lib.msda_hip_abi_version() == _lib.ABI_VERSION == 1
     assert _lib.variants("forward") == ["auto", "msda_fwd_generic", "msda_fwd_lanegroup", "msda_fwd_tiled",
                                         "msda_fwd_tiled_l0", "msda_fwd_tiled_l0big", "msda_fwd_lgcl", "msda_fwd_lg3", "msda_fwd_lgp",
-                                        "msda_fwd_win", "msda_fwd_win2", "msda_fwd_win3"]
+                                        "msda_fwd_win", "msda_fwd_win2", "msda_fwd_win3", "msda_fwd_win4"]
     assert _lib.variants("backward")[:4] == ["auto", "msda_bwd_generic", "msda_bwd_lanegroup", "msda_bwd_tiled"]
     with pytest.raises(ValueError):
         _lib.set_variant("forward", 99)

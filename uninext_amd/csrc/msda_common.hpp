@@ -99,7 +99,7 @@ inline int ensure_dynamic_lds(const void* kernel, int bytes, std::atomic<uint64_
 
 // Variant numbering shared with include/msda_hip.h.
 enum Variant { kAuto = 0, kGeneric = 1, kLaneGroup = 2, kTiled = 3, kTiledL0 = 4, kTiledL0Big = 5, kLaneGroupCL = 6,
-               kLaneGroupL3 = 7, kLaneGroupP = 8, kWin = 9, kWin2 = 10, kWin3 = 11, kNumVariants = 12 };
+               kLaneGroupL3 = 7, kLaneGroupP = 8, kWin = 9, kWin2 = 10, kWin3 = 11, kWin4 = 12, kNumVariants = 13 };
 
 // msda_fwd.hip: forward with the MSDeformAttn prologue (softmax + sampling locations) fused in.
 bool fused_forward_ok(const Dims& d, int ref_dim);
@@ -137,6 +137,10 @@ int launch_forward_win(const float* value, const int64_t* shapes, const int64_t*
 bool win2_forward_ok(const Dims& d);
 // msda_fwd_win3.hip: the persistent, software-pipelined generation (two window sets, one workgroup per CU; same preconditions).
 bool win3_forward_ok(const Dims& d);
+// msda_fwd_win4.hip: TWO lanes per (query, head) pair instead of a quad (same preconditions).
+bool win4_forward_ok(const Dims& d);
+int launch_forward_win4(const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc, const float* attn,
+                        const Dims& d, float* out, hipStream_t stream);
 int launch_forward_win3(const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc, const float* attn,
                         const Dims& d, float* out, hipStream_t stream);
 int launch_forward_win2(const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc, const float* attn,

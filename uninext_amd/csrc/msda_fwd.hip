@@ -952,6 +952,11 @@ int launch_forward<float>(int variant, const float* value, const int64_t* shapes
   // win_forward_auto follows the locality the window kernel itself reported for the latest launches
   if (variant == kAuto) variant = win_forward_auto(d, stream) ? kWin : (lg3_ok(d) ? kLaneGroupL3 : (lg ? kLaneGroup : kGeneric));
   else drop_call_context();
+  if (variant == kWin4 && !win4_forward_ok(d)) variant = lg3_ok(d) ? kLaneGroupL3 : kLaneGroup;
+  if (variant == kWin4) {
+    *kernel_name = "msda_fwd_win4";
+    return launch_forward_win4(value, shapes, lsi, loc, attn, d, out, stream);
+  }
   if (variant == kWin3 && !win3_forward_ok(d)) variant = lg3_ok(d) ? kLaneGroupL3 : kLaneGroup;
   if (variant == kWin3) {
     *kernel_name = "msda_fwd_win3";
