@@ -68,3 +68,18 @@ def test_header_symbols_and_argument_errors():
     assert lib.lsap_hip_f32(one, 2, 4, 4, one, one, one, one, None) == -2          # ld < cols
     assert lib.lsap_hip_f32(None, 4, 4, 4, one, one, one, one, None) == -1
     assert lib.lsap_hip_batch_f32(33, None, None, None, None, None, None, None, None, None) == -2
+
+
+def test_matcher_cost_header_symbols_and_argument_errors():
+    """include/matcher_cost_hip.h: the symbol is exported and the argument checks answer without a GPU."""
+    from uninext_amd import _lib
+    text = open(os.path.join(ROOT, "include", "matcher_cost_hip.h")).read()
+    assert set(re.findall(r"\b(matcher_cost_hip_\w+)\s*\(", text)) == set(_lib.MATCHER_COST_EXPORTS)
+    lib = _lib.load()
+    for sym in _lib.MATCHER_COST_EXPORTS:
+        assert hasattr(lib, sym)
+    one = 16
+    assert lib.matcher_cost_hip_f32(one, one, one, one, one, -1, 4, 4, 1.0, 1.0, 1.0, one, None) == -2
+    assert lib.matcher_cost_hip_f32(None, one, one, one, one, 4, 4, 4, 1.0, 1.0, 1.0, one, None) == -1
+    assert lib.matcher_cost_hip_f32(None, None, None, None, None, 0, 4, 4, 1.0, 1.0, 1.0, None, None) == 0     # nothing to do
+    assert b"matcher_cost" in lib.msda_hip_last_error()

@@ -11,10 +11,14 @@ from uninext_amd.matcher import HungarianMatcherVL
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("name", matcher_names())
-def test_hungarian_on_device_matches_reference(name):
+def test_hungarian_on_device_matches_reference(name, fused):
+    """fused: the cost matrix from ONE kernel (include/matcher_cost_hip.h); otherwise the PyTorch composition."""
     g, bs, outputs, targets = _case(name, device="cuda:0")
-    result = HungarianMatcherVL(cost_class=2, cost_bbox=5, cost_giou=2).forward(outputs, targets)
+    matcher = HungarianMatcherVL(cost_class=2, cost_bbox=5, cost_giou=2)
+    matcher.fused_cost = fused
+    result = matcher.forward(outputs, targets)
     for b, (i, j) in enumerate(result):
         assert np.array_equal(i.numpy(), g[f"hung_i_{b}"]) and np.array_equal(j.numpy(), g[f"hung_j_{b}"])
 
@@ -29,3 +33,38 @@ def test_ota_on_device_matches_reference(name):
         assert np.array_equal(indices[b][1].cpu().numpy(), g[f"ota_g_{b}"])
         m = matched[b].cpu().numpy() if torch.is_tensor(matched[b]) else np.asarray(matched[b], dtype=np.int64)
         assert np.array_equal(m, g[f"ota_matched_{b}"])
+
+
+def _ulps(a, b):
+    """Distance in float32 units in the last place (same-sign finite values)."""
+    ia, ib = a.view(torch.int32).to(torch.int64), b.view(torch.int32).to(torch.int64)
+    return (ia - ib).abs()
+
+
+@pytest.mark.parametrize("name", matcher_names())
+def test_fused_cost_matrix_is_the_compositions(name):
+    """matcher_cost_hip_f32 evaluates the PyTorch composition's float32 operations in its order.  Measured against ATen on
+    the MI355X (tools/matcher_cost_dbg2.py): exp, sigmoid, the L1 distance and the GIoU chain are BITWISE the composition's;
+    logf of this ROCm's device library and the one PyTorch was built with differ by one unit in the last place on a third of
+    the arguments, so the class term (a difference of two products with a log each) is held to 1e-6 absolute instead."""
+    g, bs, outputs, targets = _case(name, device="cuda:0")
+    if sum(len(t["boxes"]) for t in targets) == 0:
+        pytest.skip("no targets")
+    from uninext_amd import ext
+    from uninext_amd.matcher import box_cxcywh_to_xyxy, focal_token_cost, generalized_box_iou
+    logits = outputs["pred_logits"].flatten(0, 1)
+    boxes = outputs["pred_boxes"].flatten(0, 1)
+    tgt_map = torch.cat([t["positive_map"] for t in targets])
+    tgt_boxes = torch.cat([t["boxes"] for t in targets])
+    cls = focal_token_cost(logits.sigmoid(), tgt_map)
+    l1 = torch.cdist(boxes, tgt_boxes, p=1)
+    gi = -generalized_box_iou(box_cxcywh_to_xyxy(boxes), box_cxcywh_to_xyxy(tgt_boxes))
+    # one term at a time (the other two enter the kernel's sum as exact zeros, like here)
+    assert torch.equal(ext.matcher_cost(logits, boxes, tgt_boxes, tgt_map, 0, 1, 0), (1.0 * l1 + 0.0 * cls) + 0.0 * gi)
+    assert torch.equal(ext.matcher_cost(logits, boxes, tgt_boxes, tgt_map, 0, 0, 1), (0.0 * l1 + 0.0 * cls) + 1.0 * gi)
+    fc = ext.matcher_cost(logits, boxes, tgt_boxes, tgt_map, 1, 0, 0)
+    err = float((fc - cls).abs().max())
+    print("%s: class term max |fused - composition| %.2e (max |term| %.2f)" % (name, err, float(cls.abs().max())))
+    assert err < 1e-6
+    full = ext.matcher_cost(logits, boxes, tgt_boxes, tgt_map, 2, 5, 2)
+    assert float((full - (5 * l1 + 2 * cls + 2 * gi)).abs().max()) < 4e-6

@@ -26,6 +26,7 @@ LINEAR_EXPORTS = ("linear_hip_packed_weight_bytes", "linear_hip_pack_weight_f32"
                   "linear_hip_packed_ffn_f32")   # include/linear_hip.h
 LAYERNORM_EXPORTS = ("add_layernorm_hip_f32",)                                 # include/layernorm_hip.h
 LSAP_EXPORTS = ("lsap_hip_workspace_bytes", "lsap_hip_f32", "lsap_hip_batch_f32")   # include/lsap_hip.h
+MATCHER_COST_EXPORTS = ("matcher_cost_hip_f32",)                                # include/matcher_cost_hip.h
 LSAP_MAX_BATCH = 32
 CONV3X3_EXPORTS = ("conv3x3_hip_f32", "conv3x3_hip_packed_weight_bytes", "conv3x3_hip_pack_weight_f32",
                    "conv3x3_hip_packed_f32", "upsample_add_hip_f32")           # include/conv3x3_hip.h
@@ -75,6 +76,8 @@ def load():
     lib.lsap_hip_workspace_bytes.argtypes, lib.lsap_hip_workspace_bytes.restype = [i, i], ctypes.c_size_t
     lib.lsap_hip_f32.argtypes, lib.lsap_hip_f32.restype = [p, ctypes.c_longlong, i, i, p, p, p, p, p], i
     lib.lsap_hip_batch_f32.argtypes, lib.lsap_hip_batch_f32.restype = [i, p, p, p, p, p, p, p, p, p], i
+    f = ctypes.c_float
+    lib.matcher_cost_hip_f32.argtypes, lib.matcher_cost_hip_f32.restype = [p, p, p, p, p, i, i, i, f, f, f, p, p], i
     lib.dynmask_hip_forward_f32.argtypes = [p, p, p, p, i, i, i, i, i, i, p, p]
     lib.dynmask_hip_forward_f32.restype = i
     lib.aligned_bilinear_hip_f32.argtypes, lib.aligned_bilinear_hip_f32.restype = [p, i, i, i, i, p, p], i

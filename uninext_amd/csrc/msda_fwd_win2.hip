@@ -102,9 +102,6 @@ __device__ __forceinline__ int cvt_i32(float f) {   // saturating, NaN -> 0 (a C
 // readfirstlane of a provably uniform value is folded away, the value then stays in a VGPR, the 64-bit address arithmetic
 // that depends on it follows it into the VALU and the buffer descriptors built from it need waterfall loops.
 __device__ __forceinline__ int to_sgpr(int v) {
-#ifdef MSDA_WIN2_DBG_RFL
-  return __builtin_amdgcn_readfirstlane(v);
-#endif
   int r;
   // hazards the compiler's recogniser cannot see inside the asm (gfx940+): a VALU write of the VGPR needs a wait state
   // before v_readfirstlane reads it (without the leading s_nop most waves read a STALE register -- found the hard way);
@@ -140,13 +137,6 @@ __device__ unsigned long long g_win2_prof[kProfBlocks * kWaves * kProfSlots];
 // workgroup runs its LDS pass, ~1500 back-to-back VALU instructions per wave, and being OLDER it wins every issue slot:
 // in-kernel timestamps put the start-up at 6-7 us of a 17 us workgroup.  So: high priority until the windows are staged,
 // low priority for the throughput part.
-#ifdef MSDA_WIN2_DBG_STOP
-#define MSDA_WIN2_DBG_STOP_ MSDA_WIN2_DBG_STOP
-#define W2_STOP(n) do { if (MSDA_WIN2_DBG_STOP == (n)) return; } while (0)
-#else
-#define MSDA_WIN2_DBG_STOP_ 0
-#define W2_STOP(n) do { } while (0)
-#endif
 #ifndef MSDA_WIN2_PRIO_START
 #define MSDA_WIN2_PRIO_START 3
 #endif
@@ -157,11 +147,7 @@ __device__ unsigned long long g_win2_prof[kProfBlocks * kWaves * kProfSlots];
 // Workgroup barrier for LDS traffic only: __syncthreads() is a fence + barrier and waits for vmcnt(0) as well, i.e. for the
 // locations that are meant to stay in flight across it.  LDS operations of a CU complete in order: lgkmcnt(0) is enough.
 __device__ __forceinline__ void lds_barrier() {
-#ifdef MSDA_WIN2_SYNCTHREADS
-  __syncthreads();
-#else
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
 }
 
 struct Smp {      // one prepared NEAR sample (dead and far samples: zero weights, addresses in the zero region)
@@ -227,7 +213,6 @@ msda_fwd_win2(const float* __restrict__ value, const int64_t* __restrict__ shape
 
   const uint32_t pixB = (uint32_t)M * 128u;                // bytes from a pixel of head m to the next one
   const uint32_t hoff = (uint32_t)m * 128u;
-  W2_STOP(1);
   for (int item = kk; item < nitems;) {
     // One item per workgroup at every shape this kernel is launched on in practice, so loop-invariant code motion has
     // nothing to gain here -- but it hoists dozens of per-level / per-wave values out of the loop and spills them at once
@@ -252,7 +237,6 @@ msda_fwd_win2(const float* __restrict__ value, const int64_t* __restrict__ shape
     const int tile_ = item - b * ntiles;
     int ty = to_sgpr((int)(((float)tile_ + 0.5f) * __builtin_amdgcn_rcpf((float)TX_)));
     int tx = tile_ - ty * TX;
-    W2_STOP(2);
     const bool l0 = wv < kL0Waves;                           // a wave of the level-0 rows?
     int ogx[4], ogy[4];                                      // window origins
     int npass = 1;
@@ -264,12 +248,7 @@ msda_fwd_win2(const float* __restrict__ value, const int64_t* __restrict__ shape
 #pragma unroll
       for (int l = 0; l < 4; ++l) asm volatile("" : "+s"(lvH[l]), "+s"(lvW[l]), "+s"(lvS[l]));
       int ln;                                                // lane of the wave
-#ifdef MSDA_WIN2_DBG_TID
-      ln = threadIdx.x & 63;
-      asm volatile("" : "+v"(ln));
-#else
       asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
-#endif
       const int pq = ln >> 2, k = ln & 3;                    // quad of the wave; this lane's point / 16-byte piece
       const bool k0 = (k & 1) != 0, k1 = (k & 2) != 0;
       const int cls_a = (ln >> 3) & 1, cls_e = (ln >> 4) & 1;   // bank class of the quad: half read first, parity read first
@@ -315,25 +294,11 @@ msda_fwd_win2(const float* __restrict__ value, const int64_t* __restrict__ shape
       // ---- locations and weights of point k on the four levels (the quad reads 32 + 16 contiguous bytes per level) --
       live = live && qidx < (uint32_t)d.Lq;                  // (shapes whose pixel count exceeds num_query: never outside the tensors)
       const uint32_t pair = mul_u24_s(live ? qidx : 0u, (uint32_t)M);   // (query, head 0) pair within the image; the head sits in the base pointers
-#ifdef MSDA_WIN2_DBG_ADDR
-      {
-        const __amdgpu_buffer_rsrc_t osrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)((uint32_t)d.N * (uint32_t)d.Lq * pixB), 0x00020000);
-        const uint32_t slot = ((blockIdx.y * gridDim.x + blockIdx.x) * (uint32_t)kT + threadIdx.x) * 16u;
-        u32x4 v = {qidx, pair, (uint32_t)pair_img, (uint32_t)((uint64_t)pair_img >> 32)};
-        v[0] = (live ? 0x80000000u : 0u) | qidx;
-        __builtin_amdgcn_raw_buffer_store_b128(v, osrc, slot, 0, 0);
-        return;
-      }
-#endif
       v2f lc[4];
       float sa[4];
 #pragma unroll
       for (int l = 0; l < 4; ++l) { lc[l] = v2f{0.f, 0.f}; sa[l] = 0.f; }
-#ifdef MSDA_WIN2_DBG_NOLOAD
-      if (false) {
-#else
       if (live) {
-#endif
         const v2f* lp = reinterpret_cast<const v2f*>(loc + pair_img * 32 + (pair * 32u + 2u * (uint32_t)k));
         const float* ap = attn + pair_img * 16 + (pair * 16u + (uint32_t)k);
 #pragma unroll
@@ -344,8 +309,6 @@ msda_fwd_win2(const float* __restrict__ value, const int64_t* __restrict__ shape
       }
 
       // sample coordinates (the reference's arithmetic, cuh:282-288 and :38-46); waits for the locations
-      if (MSDA_WIN2_DBG_STOP_ == 31) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
-      W2_STOP(3);
       // (x, y) of the sample on level l in pixels, and whether it is in range
       auto coord = [&](int l, bool& in) __attribute__((always_inline)) {
         const v2f fWH = {(float)lvW[l], (float)lvH[l]};
@@ -374,20 +337,18 @@ msda_fwd_win2(const float* __restrict__ value, const int64_t* __restrict__ shape
             const int cx = cvt_i32(floorf(p.x)), cy = cvt_i32(floorf(p.y));   // (saturated garbage for poisoned locations: masked)
             px[l] = in ? cx : 0; py[l] = in ? cy : 0; pn[l] = in ? 1 : 0;
           }
-          const int ax = MSDA_WIN2_DBG_STOP_ == 322 ? px[0] : quad_scatter(px[0], px[1], px[2], px[3]);
-          const int ay = MSDA_WIN2_DBG_STOP_ == 322 ? py[1] : quad_scatter(py[0], py[1], py[2], py[3]);
-          const int an = MSDA_WIN2_DBG_STOP_ == 322 ? pn[2] : quad_scatter(pn[0], pn[1], pn[2], pn[3]);
-          if ((ln & 12) == 12 && an != 0 && MSDA_WIN2_DBG_STOP_ != 321) {
+          const int ax = quad_scatter(px[0], px[1], px[2], px[3]);
+          const int ay = quad_scatter(py[0], py[1], py[2], py[3]);
+          const int an = quad_scatter(pn[0], pn[1], pn[2], pn[3]);
+          if ((ln & 12) == 12 && an != 0) {
             atomicAdd(&mt.sum[k][0], ax);
             atomicAdd(&mt.sum[k][1], ay);
             atomicAdd(&mt.sum[k][2], an);
           }
         }
-        W2_STOP(32); W2_STOP(321); W2_STOP(322);
         W2_STAMP(4);                                         // (level-0 waves) coordinates + placement sums done
         lds_barrier();                                       // #2 (the waves of levels 1..3 arrive with their loads still in flight)
         W2_STAMP(5);
-        W2_STOP(33);
         int myOx, myOy;
         {
           const int4 sm = *reinterpret_cast<const int4*>(&mt.sum[k][0]);
@@ -407,7 +368,6 @@ msda_fwd_win2(const float* __restrict__ value, const int64_t* __restrict__ shape
           ogy[l] = __builtin_amdgcn_readlane(myOy, l);
         }
         W2_STAMP(6);                                         // origins known
-        W2_STOP(4);
       }
 
       // ---- near or far?  (near = all four corners inside the level's window, or outside the image) ------------------
@@ -532,19 +492,14 @@ msda_fwd_win2(const float* __restrict__ value, const int64_t* __restrict__ shape
         };
         if (pass == 0) {
           // the DMA depends on the origins only: the waves of levels 1..3 issue it with their own locations still in flight
-#ifndef MSDA_WIN2_DBG_NODMA
           stage_windows();
-#endif
           W2_STAMP(8);
-          W2_STOP(5);
         }
         classify();                                          // sample coordinates (the reference's arithmetic, cuh:282-288 and :38-46): waits for the locations
         W2_STAMP(9);
         // far steps while the windows travel (the first wait for far loads covers the wave's own DMA instructions, which
         // are older in the same queue)
-#ifndef MSDA_WIN2_DBG_NOFAR
         while (__ballot(fm != 0u)) far_step();
-#endif
         if (pass == 0) {
           if (tickets && tid == 0) mt.next[0] = K + (int)drawn;
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of the windows has landed
@@ -554,8 +509,6 @@ msda_fwd_win2(const float* __restrict__ value, const int64_t* __restrict__ shape
           if (ln < 16 && wv == 0) (&mt.sum[0][0])[ln] = 0;      // the next item's sums (everybody has read this item's)
         }
       }
-
-      W2_STOP(6);
       W2_STAMP(12);                                          // further far steps done
       __builtin_amdgcn_s_setprio(MSDA_WIN2_PRIO_PASS);
       // ---- near samples: 4 levels x 4 points x 4 corners x 2 halves from the LDS windows -------------------------------
@@ -693,15 +646,9 @@ msda_fwd_win2(const float* __restrict__ value, const int64_t* __restrict__ shape
         consume_half(I3{}, I2{}, s1, h2);
         consume_half(I3{}, I3{}, s1, h0);
       }
-
-      W2_STOP(7);
       W2_STAMP(13);                                          // LDS pass done
       __builtin_amdgcn_s_setprio(MSDA_WIN2_PRIO_START);
-#ifdef MSDA_WIN2_DBG_NOSTORE
-      if (false) {
-#else
       if (live) {   // a quad writes 2 x 64 contiguous bytes
-#endif
         float* op = out + pair_img * 32 + (pair * 32u + 4u * (uint32_t)k);
         __builtin_nontemporal_store(f32x4{aA0.x, aA0.y, aA1.x, aA1.y}, reinterpret_cast<f32x4*>(op + 16 * cls_a));
         __builtin_nontemporal_store(f32x4{aB0.x, aB0.y, aB1.x, aB1.y}, reinterpret_cast<f32x4*>(op + 16 * (cls_a ^ 1)));

@@ -624,6 +624,35 @@ def add_layernorm(x, residual, weight, bias, eps):
     return out
 
 
+def matcher_cost(logits, boxes, tgt_boxes, positive_map, w_class, w_bbox, w_giou):
+    """[num_pred, num_gt] fp32 cost matrix of HungarianMatcherVL.forward in one kernel (include/matcher_cost_hip.h): the same
+    float32 operations in the same order as the PyTorch composition of matcher.py:476-498.  logits [num_pred, T], boxes
+    [num_pred, 4], tgt_boxes [num_gt, 4] fp32 on one GPU; positive_map [num_gt, T] bool (or 0 / 1)."""
+    lib = _lib.load()
+    for name, t in (("logits", logits), ("boxes", boxes), ("tgt_boxes", tgt_boxes)):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.device == logits.device):
+            raise RuntimeError("matcher_cost: %s has to be a 2-d float32 tensor on the GPU of the logits" % name)
+    num_pred, T = logits.shape
+    G = tgt_boxes.shape[0]
+    if boxes.shape != (num_pred, 4) or tgt_boxes.shape[1] != 4 or tuple(positive_map.shape) != (G, T):
+        raise RuntimeError("matcher_cost: shapes do not fit together")
+    logits, boxes, tgt_boxes = logits.contiguous(), boxes.contiguous(), tgt_boxes.contiguous()
+    pm = positive_map.to(device=logits.device) != 0
+    # CSR of the positive map, built on the device (nonzero() of a row-major mask lists the tokens of a target in order)
+    tok_idx = pm.nonzero()[:, 1].to(torch.int32).contiguous()
+    tok_off = torch.zeros(G + 1, dtype=torch.int32, device=logits.device)
+    tok_off[1:] = pm.sum(1).cumsum(0).to(torch.int32)
+    cost = torch.empty((num_pred, G), dtype=torch.float32, device=logits.device)
+    with torch.cuda.device(logits.device):
+        rc = lib.matcher_cost_hip_f32(logits.data_ptr(), boxes.data_ptr(), tgt_boxes.data_ptr(), tok_off.data_ptr(),
+                                      tok_idx.data_ptr() if tok_idx.numel() else None, num_pred, T, G, float(w_class),
+                                      float(w_bbox), float(w_giou), cost.data_ptr(),
+                                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc != 0:
+        _raise(rc)
+    return cost
+
+
 def lsap_batch(costs, check=True):
     """Linear sum assignment of each 2-d fp32 GPU cost matrix in `costs` (row-major views with any row stride, e.g.
     column slices of one big matrix) on the device, with SciPy's result index for index (include/lsap_hip.h).

@@ -92,26 +92,37 @@ class HungarianMatcherVL(nn.Module):
 
     batched_topk = True   # dynamic-k selection without a host sync per ground-truth box (same indices; see the tests)
     device_lsap = True    # GPU inputs: solve the assignment on the device (include/lsap_hip.h) instead of C.cpu() + SciPy
+    fused_cost = True     # GPU fp32 inputs: the cost matrix in one kernel (include/matcher_cost_hip.h) instead of ~40 launches
 
     def __init__(self, cost_class: float = 1, cost_bbox: float = 1, cost_giou: float = 1, cost_mask: float = 1):
         super().__init__()
         self.cost_class, self.cost_bbox, self.cost_giou, self.cost_mask = cost_class, cost_bbox, cost_giou, cost_mask
         assert cost_class != 0 or cost_bbox != 0 or cost_giou != 0 or cost_mask != 0, "all costs cant be 0"
 
+    def cost_matrix(self, logits, boxes, tgt_map, tgt_boxes):
+        """[num_pred, num_gt] cost of matcher.py:476-498.  GPU fp32: one kernel with the composition's own float32
+        operation order (`fused_cost`); otherwise the composition itself."""
+        if (self.fused_cost and logits.is_cuda and logits.dtype == torch.float32 and boxes.dtype == torch.float32
+                and tgt_boxes.dtype == torch.float32 and tgt_boxes.shape[0] > 0 and tgt_map.dtype in (torch.bool, torch.uint8)):
+            from . import ext as _ext
+            xyxy, gxyxy = box_cxcywh_to_xyxy(boxes), box_cxcywh_to_xyxy(tgt_boxes)      # the reference's degenerate-box asserts
+            assert (xyxy[:, 2:] >= xyxy[:, :2]).all() and (gxyxy[:, 2:] >= gxyxy[:, :2]).all()
+            return _ext.matcher_cost(logits, boxes, tgt_boxes, tgt_map, self.cost_class, self.cost_bbox, self.cost_giou)
+        cost_class = focal_token_cost(logits.sigmoid(), tgt_map)
+        cost_bbox = torch.cdist(boxes, tgt_boxes, p=1)
+        cost_giou = -generalized_box_iou(box_cxcywh_to_xyxy(boxes), box_cxcywh_to_xyxy(tgt_boxes))
+        return self.cost_bbox * cost_bbox + self.cost_class * cost_class + self.cost_giou * cost_giou
+
     # -- Hungarian (matcher.py:449-503) ------------------------------------------------------------------
     @torch.no_grad()
     def forward(self, outputs, targets):
         """Returns a list (bs) of (index_pred int64, index_target int64), each of length min(Q, G)."""
         bs, num_queries = outputs["pred_logits"].shape[:2]
-        prob = outputs["pred_logits"].flatten(0, 1).sigmoid()
         boxes = outputs["pred_boxes"].flatten(0, 1)
         tgt_map = torch.cat([t["positive_map"] for t in targets])
         tgt_boxes = torch.cat([t["boxes"] for t in targets])
 
-        cost_class = focal_token_cost(prob, tgt_map)
-        cost_bbox = torch.cdist(boxes, tgt_boxes, p=1)
-        cost_giou = -generalized_box_iou(box_cxcywh_to_xyxy(boxes), box_cxcywh_to_xyxy(tgt_boxes))
-        cost = self.cost_bbox * cost_bbox + self.cost_class * cost_class + self.cost_giou * cost_giou
+        cost = self.cost_matrix(outputs["pred_logits"].flatten(0, 1), boxes, tgt_map, tgt_boxes)
         sizes = [len(t["boxes"]) for t in targets]
         if self.device_lsap and cost.is_cuda and cost.dtype == torch.float32:
             # SciPy's algorithm with SciPy's tie rules on the GPU: no copy of the [Q, G] matrix, no host solve; only the
