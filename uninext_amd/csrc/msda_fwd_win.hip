@@ -89,7 +89,7 @@ __device__ unsigned long long g_win_prof[kProfBlocks * kProfSlots];
 #define WIN_STAMP(i)                                                                                         \
   do {                                                                                                       \
     if (threadIdx.x == 0 && tile == g) {                                                                     \
-      const unsigned blk_ = blockIdx.x;                                             \
+      const unsigned blk_ = blockIdx.y * gridDim.x + blockIdx.x;                    \
       if (blk_ < (unsigned)kProfBlocks) g_win_prof[blk_ * kProfSlots + (i)] = __builtin_amdgcn_s_memrealtime(); \
     }                                                                                                        \
   } while (0)
@@ -164,7 +164,7 @@ __device__ __forceinline__ void win_body(const float* __restrict__ value, const 
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pq = lane >> 2;                                // quad of the wave
   const int M = d.M;
-  const int m = blockIdx.x % M, kk = blockIdx.x / M, K = gridDim.x / M;   // workgroup kk of K on head m
+  const int m = blockIdx.x, kk = blockIdx.y, K = gridDim.y;   // workgroup kk of K on head m (2-D grid: no divisions by the head count)
 
   // ---- launch constants straight from the shape tensors (uniform addresses: scalar loads, no LDS table) ------------
   int lvH[4], lvW[4], lvS[4];
@@ -650,7 +650,7 @@ __device__ __forceinline__ void win_body(const float* __restrict__ value, const 
 
 // which copy of the body a workgroup runs: the counting one for every 2^shift-th workgroup of a head
 __device__ __forceinline__ bool win_sampled(const int64_t* __restrict__ shapes, const Dims& d) {
-  const int M = d.M, kk = blockIdx.x / M, K = gridDim.x / M;
+  const int M = d.M, kk = blockIdx.y, K = gridDim.y;
   const int TY = ((int)shapes[0] + kTH - 1) / kTH, TX = ((int)shapes[1] + kTW - 1) / kTW;
   const int nitems = d.N * TY * TX;
   return (kk & ((1 << stat_shift(M * min(K, nitems))) - 1)) == 0;
@@ -920,12 +920,13 @@ int launch_forward_win(const float* value, const int64_t* shapes, const int64_t*
   // at least the tile count of any pyramid whose level 0 holds <= ~3/4 of the pixels; the surplus exits at once and the
   // dispatcher staggers the rest, which keeps the memory / LDS / VALU phases of neighbouring workgroups out of step.
   // MSDA_WIN_PERSIST=1: two resident workgroups per CU walk the items (measured slower: every workgroup of the chip
-  // enters the same phase at the same time).  Either way head m = blockIdx.x % M, i.e. (by the observed round-robin
+  // enters the same phase at the same time).  Either way head m = blockIdx.x of a 2-D grid, i.e. (by the observed round-robin
   // placement) XCD m only ever touches head m's slice of `value`.
   static const bool persist = std::getenv("MSDA_WIN_PERSIST") && std::getenv("MSDA_WIN_PERSIST")[0] == '1';
   int K = persist ? (2 * 256) / d.M : d.N * ((d.S + 127) / 128);
   if (K < 1) K = 1;
-  const dim3 grid((unsigned)(d.M * K), 1u);
+  if (K > 65535) K = 65535;                                 // (grid y extent; a workgroup then walks items kk, kk + K, ...)
+  const dim3 grid((unsigned)d.M, (unsigned)K);
   hipLaunchKernelGGL(kern, grid, dim3(kT), kLdsBytes, stream, value, shapes, lsi, loc, attn, d, out, la);
   const int rc = (int)hipGetLastError();
   if (stat && rc == 0) (void)hipEventRecord(ev, stream);
@@ -945,7 +946,8 @@ int launch_forward_win_fused(const float* value, int head_major, const int64_t* 
     return rc;
   int K = d.N * ((d.S + 127) / 128);                        // as in launch_forward_win
   if (K < 1) K = 1;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(d.M * K), 1u), dim3(kT), kLdsBytes, stream, value, head_major, shapes, lsi,
+  if (K > 65535) K = 65535;
+  hipLaunchKernelGGL(kern, dim3((unsigned)d.M, (unsigned)K), dim3(kT), kLdsBytes, stream, value, head_major, shapes, lsi,
                      ref_points, offsets, logits, d, out, la);
   const int rc = (int)hipGetLastError();
   if (stat && rc == 0) (void)hipEventRecord(ev, stream);
