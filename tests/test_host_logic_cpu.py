@@ -127,3 +127,49 @@ def test_named_workloads_cover_the_baseline_configs():
         assert x["value"].shape == (w["batch"], S, 8, 32)
         assert x["loc"].shape[1] == (w["num_query"] or S)
         assert int(x["lsi"][-1]) + w["levels"][-1][0] * w["levels"][-1][1] == S
+
+
+def test_call_sites_nest_and_travel_with_the_autograd_function():
+    """uninext_amd.ext.call_site: a thread-local, nesting context (the library chooses its encoder kernels per call site,
+    include/msda_hip.h); MSDeformAttnFunction records the site of its forward and re-enters it in backward -- on the host
+    path here, where the context is not used but the plumbing is the same."""
+    import threading
+
+    import torch
+
+    from uninext_amd import ext
+    from uninext_amd.functions import MSDeformAttnFunction
+    assert ext.current_call_site() == 0
+    with ext.call_site(7):
+        assert ext.current_call_site() == 7
+        with ext.call_site(9):
+            assert ext.current_call_site() == 9
+        assert ext.current_call_site() == 7
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(ext.current_call_site()))
+        t.start(); t.join()
+        assert seen == [0]                                    # per thread
+    assert ext.current_call_site() == 0
+
+    shapes = torch.tensor([[4, 5], [2, 3]], dtype=torch.int64)
+    lsi = torch.tensor([0, 20], dtype=torch.int64)
+    g = torch.Generator().manual_seed(0)
+    value = torch.rand(1, 26, 2, 8, generator=g, requires_grad=True)
+    loc = torch.rand(1, 3, 2, 2, 2, 2, generator=g, requires_grad=True)
+    attn = torch.softmax(torch.rand(1, 3, 2, 4, generator=g), -1).view(1, 3, 2, 2, 2).requires_grad_(True)
+    recorded = []
+    real_backward = ext.ms_deform_attn_backward
+
+    def spy(*args):
+        recorded.append(ext.current_call_site())
+        return real_backward(*args)
+
+    ext.ms_deform_attn_backward, saved = spy, ext.ms_deform_attn_backward
+    try:
+        with ext.call_site(5):
+            out = MSDeformAttnFunction.apply(value, shapes, lsi, loc, attn, 64)
+        out.sum().backward()                                  # outside of the block
+    finally:
+        ext.ms_deform_attn_backward = saved
+    assert recorded == [5]
+    assert value.grad is not None and loc.grad is not None and attn.grad is not None
