@@ -403,9 +403,17 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
       {
         const uint32_t farbits = inb & ~nb;
         const int ch = ln & 31;
-        auto half_sum = [](float v) __attribute__((always_inline)) {     // over the 32 lanes of a half; every lane gets the total
-#pragma unroll
-          for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        // over the 32 lanes of a half; every lane gets the total: four DPP butterfly steps inside a row of 16 lanes and ONE
+        // cross-row exchange (as a shuffle loop it was a chain of five dependent ds_bpermute round trips per value).
+        // (Tried and dropped: software-pipelining this loop -- the next iteration's loads issued before this one's are
+        // waited for -- changed nothing, 342.6 vs 342 us and 1145 vs 1139 us on the wide flavour: the loop is bound by its
+        // four full-line atomics per sample, not by the round trips of its loads.)
+        auto half_sum = [](float v) __attribute__((always_inline)) {
+          v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+          v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+          v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+          v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));   // row_mirror
+          v += __shfl_xor(v, 16, 64);
           return v;
         };
 #pragma unroll
