@@ -609,19 +609,12 @@ msda_fwd_lg3(const float* __restrict__ value, const int64_t* __restrict__ shapes
       o[1] = sm.ok2 ? a1 + 128u : zero_slot;
       o[2] = sm.ok3 ? a1 + (uint32_t)W * 128u : zero_slot;
       o[3] = sm.ok4 ? a1 + (uint32_t)(W + 1) * 128u : zero_slot;
-      // bank conflicts of the LDS gather (round 3; r02 counters: 79 % of this kernel's LDS-active cycles): a pair's eight
-      // lanes read the 128 bytes of ONE pixel slot, a 16-lane service group of ds_read_b128 holds two pairs, and two slots of
-      // the same parity (address bit 7) share their banks.  The two x-neighbours of a corner row have opposite parities:
-      // the even pair of a service group reads the even slot of each row first, the odd pair the odd one.
-      const uint32_t cls = (uint32_t)g & 1u;
-      if ((((a1 >> 7) ^ cls) & 1u) != 0u) {
-        const uint32_t t = o[0]; o[0] = o[1]; o[1] = t;
-        const float tw = w.x; w.x = w.y; w.y = tw;
-      }
-      if (((((a1 >> 7) + (uint32_t)W) ^ cls) & 1u) != 0u) {
-        const uint32_t t = o[2]; o[2] = o[3]; o[3] = t;
-        const float tw = w.z; w.z = w.w; w.w = tw;
-      }
+      // (round 3, tried and taken out again: the two pairs of a 16-lane ds_read_b128 service group read two pixel slots, which
+      // share their banks when the slots have the same parity -- r02 counters: conflicts on 79 % of this kernel's LDS-active
+      // cycles.  Letting the even pair read the even slot of each corner row first and the odd pair the odd one brought that
+      // to 45 %, but the two conditional swaps cost three registers the kernel does not have at 64: 12 bytes of scratch per
+      // lane, HBM traffic 213 -> 255 MB and 126 -> 138-143 us on the wide / uniform flavours.  LDS-active cycles are 1 % of
+      // the kernel's wave cycles.)
     } else {
       const uint32_t o1 = (uint32_t)pix1 * pix_bytes;
       o[0] = sm.ok1 ? o1 : kOobOffset;
