@@ -6,6 +6,9 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/ev
 rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
+# traffic first: bench.py quotes profiles/traffic.json when kernel names and source hash match its own run
+timeout 900 python tools/measure_traffic.py --out $O/traffic.json --sq $O/sq_pmc.txt --workdir $O/traffic_prof > $O/measure_traffic.log 2>&1
+cp $O/traffic.json profiles/traffic.json
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
 ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace_noextras -- python $R/bench.py --no-cpu-baseline --no-extras > $O/trace_noextras.json 2> $O/trace_noextras.err )
 python tools/rocprof_summary.py trace $(find $O/trace_noextras -name "*_results.db" | head -1) > $O/bench_kernel_trace_noextras.txt 2>&1
@@ -13,7 +16,6 @@ cat $O/trace_noextras.json >> $O/bench_kernel_trace_noextras.txt
 ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace_full -- python $R/bench.py --no-cpu-baseline > $O/trace_full.json 2> $O/trace_full.err )
 python tools/rocprof_summary.py trace $(find $O/trace_full -name "*_results.db" | head -1) > $O/bench_kernel_trace.txt 2>&1
 cat $O/trace_full.json >> $O/bench_kernel_trace.txt
-timeout 900 python tools/measure_traffic.py --out $O/traffic.json --sq $O/sq_pmc.txt --workdir $O/traffic_prof > $O/measure_traffic.log 2>&1
 timeout 600 python tools/kbench.py --reps 18 --rotate 6 --variants-fwd 7,9,10,11,12 --variants-bwd 3,4 --flavours model,wide,uniform > $O/kbench_final.txt 2>&1
 timeout 900 python tools/kbench.py --reps 12 --rotate 3 --workloads all --flavours model,wide > $O/kbench_workloads.txt 2>&1
 rm -rf $O/trace_noextras $O/trace_full $O/traffic_prof
