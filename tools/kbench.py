@@ -17,9 +17,18 @@ sys.path.insert(0, ROOT)
 from uninext_amd import _lib, ext, workloads  # noqa: E402
 
 
-def timeit(fn, reps):
-    for _ in range(3):
+def timeit(fn, reps, warm_ms=60.0):
+    # warm up by TIME, not by count: the first launches of a process (and the first after an idle gap) run at a lower
+    # clock -- with three warm-up launches the first variant of a list came out 8-12 % slower than the same kernel measured
+    # after another one (round 3: an A/B "gain" of 10 % turned out to be the order of the runs)
+    import time
+    t0 = time.perf_counter()
+    n = 0
+    while n < 3 or (time.perf_counter() - t0) * 1e3 < warm_ms:
         fn()
+        n += 1
+        if n % 8 == 0:
+            torch.cuda.synchronize()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
