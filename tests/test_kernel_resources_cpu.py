@@ -24,6 +24,7 @@ LIMITS = {
     "msda_bwd_win.hip": {"msda::msda_bwd_win": (168, 0)},
     "msda_bwd_tiled.hip": {"msda::msda_bwd_tiled": (168, 0)},
     "msda_bwd.hip": {"msda::msda_bwd_generic<float, 1>": (96, 0)},
+    "msda_bwd_dec.hip": {"msda::msda_bwd_dec": (128, 0)},
 }
 
 

@@ -381,13 +381,15 @@ def test_tiled_backward_fixed_point_bound_under_high_dynamic_range(kernel, dev, 
     assert float(err_f.max()) < 1e-5 * gmax
 
 
-def test_full_size_decoder_backward_every_query(dev, api):
+@pytest.mark.parametrize("kernel", ["msda_bwd_dec", "msda_bwd_generic"])
+def test_full_size_decoder_backward_every_query(kernel, dev, api):
     from oracle import msda_oracle
     from uninext_amd import workloads
     MSDA, lib = api
     x = workloads.make_inputs("decoder", "model", batch=2, seed=23, device=dev)
     go = torch.randn(2, 900, 256, generator=torch.Generator().manual_seed(24)).to(dev)
-    gv, gl, ga = MSDA.ms_deform_attn_backward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], go, 64)
+    gv, gl, ga = _bwd(MSDA, lib, x, go, kernel)
+    assert lib.last_kernel("backward") == kernel
     ogv, ogl, oga = msda_oracle.backward(go, x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
     tgv, _, tga = msda_oracle.backward(go.double(), x["value"].double(), x["shapes"], x["lsi"], x["loc"].double(), x["attn"].double())
     # decoder queries pile up on few pixels (random boxes): grad_value reaches the hundreds, so its bound, like
@@ -564,3 +566,66 @@ def test_fused_encoder_forward_window_and_gather_kernels(ref_dim, head_major, de
         assert lib.last_kernel("forward") == kernel
         err = float(np.abs(out.cpu().numpy().astype(np.float64) - want).max())
         assert err < 1e-4, (variant, err)
+
+
+DECODER_PYRAMIDS = [
+    ((100, 168), (50, 84), (25, 42), (13, 21)),      # R50 training: level 3 and 23 of the 25 rows of level 2 in LDS
+    ((40, 40), (80, 80), (30, 30), (50, 50)),        # a last level larger than the accumulators: 24 of its 50 rows, none of level 2
+    ((3, 400), (2, 200), (1, 100), (1, 50)),         # one-row levels
+    ((12, 12), (6, 6), (3, 3), (2, 2)),              # everything tiny
+]
+
+
+@pytest.mark.parametrize("num_query", [64, 333, 1100])
+@pytest.mark.parametrize("levels", DECODER_PYRAMIDS)
+def test_decoder_backward_kernel_on_other_pyramids_and_query_counts(levels, num_query, dev, api):
+    """msda_bwd_dec keeps whole rows of level 3, then level 2, in LDS accumulators and slices the queries over workgroups:
+    pyramids whose coarse levels do not fit, query counts that do not divide, every element against the oracle."""
+    from oracle import msda_oracle
+    from uninext_amd import workloads
+    MSDA, lib = api
+    x = workloads.make_inputs("decoder", "model", batch=3, levels=levels, num_query=num_query, heads=5, seed=81, device=dev)
+    go = torch.randn(3, num_query, 160, generator=torch.Generator().manual_seed(82)).to(dev)
+    gv, gl, ga = _bwd(MSDA, lib, x, go, "msda_bwd_dec")
+    assert lib.last_kernel("backward") == "msda_bwd_dec"
+    ogv, ogl, oga = msda_oracle.backward(go, x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
+    tgv, _, tga = msda_oracle.backward(go.double(), x["value"].double(), x["shapes"], x["lsi"], x["loc"].double(), x["attn"].double())
+    e_gv = float(np.abs(gv.cpu().numpy().astype(np.float64) - tgv).max())
+    e_ga = float(np.abs(ga.cpu().numpy().astype(np.float64) - tga).max())
+    o_gv, o_ga = float(np.abs(ogv - tgv).max()), float(np.abs(oga - tga).max())
+    assert e_gv < max(1e-4, 2.0 * o_gv), (e_gv, o_gv)
+    assert e_ga < max(1e-4, 2.0 * o_ga), (e_ga, o_ga)
+    d_gl = np.abs(gl.cpu().numpy().astype(np.float64) - ogl)
+    for l, (h, w) in enumerate(levels):
+        assert float(d_gl[:, :, :, l].max()) < 1e-4 * max(h, w, 10), (l, float(d_gl[:, :, :, l].max()))
+
+
+def test_decoder_backward_fixed_point_bound_and_non_finite_inputs(dev, api):
+    """The LDS accumulators of msda_bwd_dec are fixed point with a per-workgroup scale from (#queries of the slice x 4) x
+    max |grad_out| x max |attn|: upstream gradients with 8 decades of dynamic range stay within the documented step of the
+    LARGEST one, and a NaN / Inf upstream gradient switches its workgroup to float atomics and propagates like the
+    reference's."""
+    from oracle import msda_oracle
+    from uninext_amd import workloads
+    MSDA, lib = api
+    x = workloads.make_inputs("decoder", "model", batch=2, num_query=1100, seed=83, device=dev)
+    g = torch.Generator().manual_seed(84)
+    mag = 10.0 ** (torch.rand(2, 1100, 1, generator=g) * 8.0 - 4.0)
+    go = (torch.randn(2, 1100, 256, generator=g) * mag).to(dev)
+    gmax = float(go.abs().max())
+    tgv, _, _ = msda_oracle.backward(go.double(), x["value"].double(), x["shapes"], x["lsi"], x["loc"].double(), x["attn"].double())
+    gv, _, _ = _bwd(MSDA, lib, x, go, "msda_bwd_dec")
+    assert lib.last_kernel("backward") == "msda_bwd_dec"
+    err = float(np.abs(gv.cpu().numpy().astype(np.float64) - tgv).max())
+    step = gmax * 2.0 ** -21          # <= 69 queries x 4 samples per accumulator and slice: the scale leaves >= 21 bits below max |grad_out|
+    print("msda_bwd_dec: max |err| %.3e = %.1f steps of 2^-21 max|grad_out|" % (err, err / step))
+    assert err < 64.0 * step
+    go2 = go.clone()
+    go2[0, 5, 40] = float("nan")
+    go2[1, 700, 3] = float("inf")
+    gv2, gl2, ga2 = _bwd(MSDA, lib, x, go2, "msda_bwd_dec")
+    ref = _bwd(MSDA, lib, x, go2, "msda_bwd_generic")
+    for a, b in zip((gv2, gl2, ga2), ref):
+        assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.isinf(a), torch.isinf(b))
+    fin = torch.isfinite(ref[0])
+    assert float((gv2[fin] - ref[0][fin]).abs().max()) < 64.0 * step

@@ -1,0 +1,193 @@
+// msda_bwd_dec -- MSDeformAttn backward for decoder-style calls (few queries, many pixels): fp32, D = 32, L = P = 4.
+// gfx950 only.  Replaces, for these calls, the work of ops/src/cuda/ms_deform_im2col_cuda.cuh:301-403 / :406-920.
+//
+// The decoder backward is bound by its value-gradient atomics: 1100 queries x 8 heads x 16 samples x 4 corners = one
+// full-line L2 atomic each (msda_bwd_generic: 1.13 M per call, 116 us).  Half of them go to the two COARSE levels, whose
+// pixels are few (R50: 1050 + 273 per head) and hit again and again.  Here a workgroup owns (image, head, slice of the
+// queries) and keeps int32 accumulators for as many whole rows of level 3, then level 2, as fit 150 KB of LDS: the
+// corner adds of those rows are ds_add_u32 (fixed point with a per-workgroup power-of-two scale from a bound that cannot
+// overflow, as msda_bwd_tiled), and every touched accumulator row leaves once, as one full-line float atomic.  Levels 0
+// and 1 (and rows that did not fit) take the direct atomics of msda_bwd_generic; grad_sampling_loc / grad_attn_weight
+// are computed as there (half a wave per pair, lane = channel, DPP sums), every element written once.
+#include <cmath>
+#include <cstdlib>
+
+#include "msda_common.hpp"
+
+namespace msda {
+namespace {
+
+constexpr int kDT = 1024;                                  // threads per workgroup = 32 half-waves = 32 pairs in flight
+constexpr int kAccSlots = 1200;                            // accumulator slots (pixels) of 32 int32: 150 KB
+struct DMeta { unsigned gmax_bits, amax_bits; };
+constexpr int kDecLds = kAccSlots * 128 + 16;
+
+__device__ __forceinline__ float half_sum(float f) {       // over the 32 lanes of a half wave; every lane gets the total
+  f += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(f), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  f += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(f), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  f += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(f), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  f += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(f), 0x140, 0xF, 0xF, true));   // row_mirror
+  f += __shfl_xor(f, 16, 64);
+  return f;
+}
+__device__ __forceinline__ float abs_or_inf(float v) {     // |v|, +inf for NaN: non-finite inputs must reach the bound
+  const float a = fabsf(v);
+  return a == a ? a : __builtin_inff();
+}
+
+}  // namespace
+
+__global__ void __launch_bounds__(kDT)
+msda_bwd_dec(const float* __restrict__ grad_out, const float* __restrict__ value, const int64_t* __restrict__ shapes,
+             const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ attn, Dims d,
+             float* __restrict__ grad_value, float* __restrict__ grad_loc, float* __restrict__ grad_attn) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* const acc = reinterpret_cast<int*>(smem);                         // [kAccSlots][32]
+  DMeta& mt = *reinterpret_cast<DMeta*>(smem + kAccSlots * 128);
+  const int tid = threadIdx.x, lane = tid & 31, hw = tid >> 5;           // half wave hw of 32
+  const int m = blockIdx.x, sl = blockIdx.y, nsl = gridDim.y, b = blockIdx.z;
+  const int M = d.M;
+  int H[4], W[4], S0[4];
+#pragma unroll
+  for (int l = 0; l < 4; ++l) { H[l] = (int)shapes[2 * l]; W[l] = (int)shapes[2 * l + 1]; S0[l] = (int)lsi[l]; }
+  // whole rows of level 3, then of level 2, that fit the accumulator slots (rows 0 .. rows - 1 of each)
+  const int rows3 = min(H[3], kAccSlots / max(W[3], 1));
+  const int base2 = rows3 * W[3];
+  const int rows2 = min(H[2], (kAccSlots - base2) / max(W[2], 1));
+  const int nslots = base2 + rows2 * W[2];
+  // this workgroup's queries
+  const int qper = (d.Lq + nsl - 1) / nsl;
+  const int q0 = sl * qper, q1 = min(d.Lq, q0 + qper);
+
+  for (int o = tid * 4; o < nslots * 32; o += kDT * 4) *reinterpret_cast<int4*>(acc + o) = make_int4(0, 0, 0, 0);
+  if (tid == 0) { mt.gmax_bits = 0u; mt.amax_bits = 0u; }
+  __syncthreads();
+  // ---- the bound of the fixed-point scale: max |grad_out| and max |attn| over the workgroup's pairs -----------------------
+  {
+    float gm = 0.f, am = 0.f;
+    for (int q = q0 + hw; q < q1; q += kDT / 32) {
+      const int64_t pair = ((int64_t)b * d.Lq + q) * M + m;
+      gm = fmaxf(gm, abs_or_inf(grad_out[pair * 32 + lane]));
+      if (lane < 16) am = fmaxf(am, abs_or_inf(attn[pair * 16 + lane]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { gm = fmaxf(gm, __shfl_xor(gm, o, 64)); am = fmaxf(am, __shfl_xor(am, o, 64)); }
+    if ((tid & 63) == 0) {   // non-negative floats order like their bit patterns
+      atomicMax(&mt.gmax_bits, __float_as_uint(gm));
+      atomicMax(&mt.amax_bits, __float_as_uint(am));
+    }
+  }
+  __syncthreads();
+  // an accumulator receives at most one corner of each level-l sample of the slice: (q1 - q0) * 4 adds of at most
+  // max |grad_out| * max |attn| each (bilinear weights <= 1)
+  const float bound = (float)(max(q1 - q0, 1) * 4) * __uint_as_float(mt.gmax_bits) * __uint_as_float(mt.amax_bits);
+  const bool use_lds = bound <= 3.402823466e+38f && nslots > 0;          // false for NaN / Inf: everything takes float atomics
+  float scale = 1.f, inv_scale = 1.f;
+  if (use_lds && bound > 0.f) {
+    int e;
+    (void)frexpf(bound, &e);                                             // bound < 2^e
+    e = max(-90, min(90, 30 - e));
+    scale = ldexpf(1.f, e);
+    inv_scale = ldexpf(1.f, -e);
+  }
+
+  const int64_t pix_stride = (int64_t)M * 32;
+  for (int q = q0 + hw; ; q += kDT / 32) {
+    // the two halves of a wave run in lock step: a half past the end idles through the loop with `live` off
+    const bool live = q < q1;
+    if (!__ballot(live)) break;
+    const int64_t pair = ((int64_t)b * d.Lq + (live ? q : q0)) * M + m;
+    const float g = live ? grad_out[pair * 32 + lane] : 0.f;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      const int Hl = H[l], Wl = W[l];
+      const int64_t lvl_off = ((int64_t)b * d.S + S0[l]) * pix_stride + (int64_t)m * 32 + lane;
+      // accumulator rows of this level (none on levels 0 and 1)
+      const int rows_l = use_lds ? (l == 3 ? rows3 : l == 2 ? rows2 : 0) : 0;
+      const int slot0 = l == 3 ? 0 : base2;
+      Sample<float> s[4];
+      float a[4], v[4][4];
+      int64_t o1[4];
+      bool in[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {                          // the four points of the level: 16 corner loads in flight
+        const int64_t si = pair * 16 + l * 4 + k;
+        a[k] = attn[si];
+        s[k] = make_sample<float>(loc[si * 2], loc[si * 2 + 1], Hl, Wl);
+        in[k] = live && s[k].in_range;
+        o1[k] = lvl_off + ((int64_t)s[k].h_low * Wl + s[k].w_low) * pix_stride;
+        v[k][0] = (in[k] && s[k].ok1) ? value[o1[k]] : 0.f;
+        v[k][1] = (in[k] && s[k].ok2) ? value[o1[k] + pix_stride] : 0.f;
+        v[k][2] = (in[k] && s[k].ok3) ? value[o1[k] + (int64_t)Wl * pix_stride] : 0.f;
+        v[k][3] = (in[k] && s[k].ok4) ? value[o1[k] + (int64_t)Wl * pix_stride + pix_stride] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int64_t si = pair * 16 + l * 4 + k;
+        float pa = 0.f, pw = 0.f, ph = 0.f;
+        if (__ballot(in[k])) {                               // wave-uniform (the sums need every lane of the half)
+          if (in[k]) {
+            const Sample<float>& t = s[k];
+            const float tgv = g * a[k];
+            const float w1 = t.hh * t.hw, w2 = t.hh * t.lw, w3 = t.lh * t.hw, w4 = t.lh * t.lw;
+            const int64_t o3 = o1[k] + (int64_t)Wl * pix_stride;
+            // a corner on an accumulator row: fixed-point LDS add; otherwise the direct full-line atomic
+            const bool top_acc = t.h_low >= 0 && t.h_low < rows_l, bot_acc = t.h_low + 1 < rows_l;
+            int* const at = acc + (slot0 + t.h_low * Wl + t.w_low) * 32 + lane;
+            if (t.ok1) { if (top_acc) atomicAdd(at, __float2int_rn(w1 * tgv * scale)); else atomic_add(grad_value + o1[k], w1 * tgv); }
+            if (t.ok2) { if (top_acc) atomicAdd(at + 32, __float2int_rn(w2 * tgv * scale)); else atomic_add(grad_value + o1[k] + pix_stride, w2 * tgv); }
+            if (t.ok3) { if (bot_acc) atomicAdd(at + Wl * 32, __float2int_rn(w3 * tgv * scale)); else atomic_add(grad_value + o3, w3 * tgv); }
+            if (t.ok4) { if (bot_acc) atomicAdd(at + Wl * 32 + 32, __float2int_rn(w4 * tgv * scale)); else atomic_add(grad_value + o3 + pix_stride, w4 * tgv); }
+            pa = g * (w1 * v[k][0] + w2 * v[k][1] + w3 * v[k][2] + w4 * v[k][3]);
+            pw = tgv * (t.hh * (v[k][1] - v[k][0]) + t.lh * (v[k][3] - v[k][2]));
+            ph = tgv * (t.hw * (v[k][2] - v[k][0]) + t.lw * (v[k][3] - v[k][1]));
+          }
+          pa = half_sum(pa);
+          pw = half_sum(pw);
+          ph = half_sum(ph);
+        }
+        if (live && lane == 0) {
+          grad_attn[si] = pa;
+          grad_loc[si * 2] = (float)Wl * pw;
+          grad_loc[si * 2 + 1] = (float)Hl * ph;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- flush: every touched accumulator row of 32 channels leaves as one full-line float atomic --------------------------
+  if (use_lds) {
+    for (int slot = hw; slot < nslots; slot += kDT / 32) {
+      const int raw = acc[slot * 32 + lane];
+      const unsigned long long any = __ballot(raw != 0) >> (tid & 32) & 0xffffffffull;
+      if (any) {
+        const int pix = slot < base2 ? S0[3] + slot : S0[2] + (slot - base2);
+        atomic_add(grad_value + ((int64_t)b * d.S + pix) * pix_stride + (int64_t)m * 32 + lane, (float)raw * inv_scale);
+      }
+    }
+  }
+}
+
+bool dec_backward_ok(const Dims& d) {
+  return d.D == 32 && d.L == 4 && d.P == 4 && d.Lq >= 64 && d.M <= 65535 && d.N <= 65535;
+}
+
+int launch_backward_dec(const float* grad_out, const float* value, const int64_t* shapes, const int64_t* lsi,
+                        const float* loc, const float* attn, const Dims& d, float* grad_value, float* grad_loc,
+                        float* grad_attn, hipStream_t stream) {
+  static std::atomic<uint64_t> lds_opted_in{0};
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(msda_bwd_dec), kDecLds, lds_opted_in)) return rc;
+  // slices of the queries per (image, head): enough workgroups to cover the chip once, at most 16 (every slice flushes its own
+  // accumulators).  MSDA_BWD_DEC_SLICES=n: A/B switch.
+  static const int env = std::getenv("MSDA_BWD_DEC_SLICES") ? std::atoi(std::getenv("MSDA_BWD_DEC_SLICES")) : 0;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  int nsl = env > 0 ? env : (cus + d.M * d.N - 1) / (d.M * d.N);
+  nsl = std::max(1, std::min(nsl, 16));
+  nsl = std::min(nsl, (d.Lq + 31) / 32);
+  hipLaunchKernelGGL(msda_bwd_dec, dim3((unsigned)d.M, (unsigned)nsl, (unsigned)d.N), dim3(kDT), kDecLds, stream, grad_out, value,
+                     shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn);
+  return (int)hipGetLastError();
+}
+
+}  // namespace msda

@@ -116,6 +116,10 @@ int launch_backward_tiled(const float* grad_out, const float* value, const int64
 
 // msda_bwd_win.hip: encoder backward with value AND gradient windows in LDS (fp32, D = 32, L = P = 4, Lq == S).
 bool win_backward_ok(const Dims& d);
+// msda_bwd_dec.hip: decoder-style calls (fp32, D = 32, L = P = 4) with LDS accumulators for the coarse levels
+bool dec_backward_ok(const Dims& d);
+int launch_backward_dec(const float* grad_out, const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc,
+                        const float* attn, const Dims& d, float* grad_value, float* grad_loc, float* grad_attn, hipStream_t stream);
 int launch_backward_win(const float* grad_out, const float* value, const int64_t* shapes, const int64_t* lsi,
                         const float* loc, const float* attn, const Dims& d, float* grad_value, float* grad_loc,
                         float* grad_attn, hipStream_t stream);
