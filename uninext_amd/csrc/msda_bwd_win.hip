@@ -191,7 +191,7 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
   static_assert(kSlots <= kT, "one slot-table entry per thread");
   for (int o = tid * 16; o < kSlots * 128; o += kT * 16) *reinterpret_cast<f32x4*>(smem + kAccOff + o) = f32x4{0.f, 0.f, 0.f, 0.f};
   if (tid >= 640 && tid < 656) (&mt.sum[0][0])[tid - 640] = 0;
-  if (tid == 656) { mt.gmax_bits = 0u; mt.amax_bits = 0u; mt.pad0 = 0u; }
+  if (tid == 656) { mt.gmax_bits = 0u; mt.amax_bits = 0u; }   // (pad0: written by the fetch of every item's first pass before it is read)
 
   const uint32_t pixB = (uint32_t)M * 128u;                // bytes from a pixel of head m to the next one
   const uint32_t hoff = (uint32_t)m * 128u;
@@ -473,7 +473,7 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
         BW_STAMP(9);
         // the next item's placement sums and scale words (everybody has read this item's; the next adds come after barrier #1)
         if (tid < 16) (&mt.sum[0][0])[tid] = 0;
-        if (tid == 16) { mt.gmax_bits = 0u; mt.amax_bits = 0u; mt.pad0 = 0u; }
+        if (tid == 16) { mt.gmax_bits = 0u; mt.amax_bits = 0u; }   // (pad0 is rewritten for every item, before barrier #4 of the one before)
       }
 
       if (!l0) __builtin_amdgcn_s_setprio(2);                  // the three youngest waves of the workgroup would finish the pass last
@@ -607,14 +607,13 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
     }
 
     const bool last = !body || pass + 1 >= npass;
-    if (body && last) {
-      BW_STAMP(11);
-      lds_barrier();                                           // #4: every wave's atomics are in
-      BW_STAMP(12);
-    }
+    BW_STAMP(11);
     // ---- the next step: its query, and its loads issued ---------------------------------------------------------------------
     const int nitem = last ? item + K : item, np = last ? 0 : pass + 1;
     const bool more = nitem < nitems;
+    // the three youngest waves derive their queries in float + five ds_bpermute and are the last to have their loads out:
+    // they go ahead of the other waves' flush (312.8 -> 308.6 us, A/B on one box)
+    if (!l0) __builtin_amdgcn_s_setprio(2);
     if (more) {
       const int b2 = to_sgpr((int)(((float)nitem + 0.5f) * __builtin_amdgcn_rcpf((float)ntiles)));
       const int64_t pair_img2 = (int64_t)b2 * d.Lq * M + m;
@@ -676,8 +675,13 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
         }
 
     }
+    __builtin_amdgcn_s_setprio(0);
     BW_STAMP(14);
     if (body && last) {
+      // #4: every wave's atomics are in.  The next item's queries and loads above do not depend on it: the waves of levels 1..3,
+      // which finish the pass first, derive theirs while the level-0 waves are still in the pass instead of behind the barrier.
+      lds_barrier();
+      BW_STAMP(12);
       // ---- flush: every touched accumulator pixel inside the image leaves as one full-line float atomic (32 lanes x 4 B) ----
       {
         const int ch = tid & 31;
