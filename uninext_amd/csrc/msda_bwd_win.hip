@@ -398,73 +398,6 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
       }
       float ga[4] = {0.f, 0.f, 0.f, 0.f}, glx[4] = {0.f, 0.f, 0.f, 0.f}, gly[4] = {0.f, 0.f, 0.f, 0.f};
 
-      // ---- far samples: a HALF of the wave per sample (lane = channel), two samples per iteration; the corner loads of an
-      // iteration are all in flight before anything waits for them ------------------------------------------------------------
-      {
-        const uint32_t farbits = inb & ~nb;
-        const int ch = ln & 31;
-        // over the 32 lanes of a half; every lane gets the total: four DPP butterfly steps inside a row of 16 lanes and ONE
-        // cross-row exchange (as a shuffle loop it was a chain of five dependent ds_bpermute round trips per value).
-        // (Tried and dropped: software-pipelining this loop -- the next iteration's loads issued before this one's are
-        // waited for -- changed nothing, 342.6 vs 342 us and 1145 vs 1139 us on the wide flavour: the loop is bound by its
-        // four full-line atomics per sample, not by the round trips of its loads.)
-        auto half_sum = [](float v) __attribute__((always_inline)) {
-          v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
-          v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
-          v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
-          v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));   // row_mirror
-          v += __shfl_xor(v, 16, 64);
-          return v;
-        };
-#pragma unroll
-        for (int l = 0; l < 4; ++l) {
-          uint64_t fm = __ballot(((farbits >> l) & 1u) != 0u);
-          const int Hl = lvH[l], Wl = lvW[l], Sl = lvS[l];
-          while (fm) {
-            const int sA = __builtin_ctzll(fm);
-            fm &= fm - 1;
-            const bool hasB = fm != 0;
-            const int sB = hasB ? __builtin_ctzll(fm) : sA;
-            if (hasB) fm &= fm - 1;
-            const bool act = (ln < 32) | hasB;
-            const int src = (ln < 32 ? sA : sB) << 2;
-            const float fx = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(xy[l].x)));
-            const float fy = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(xy[l].y)));
-            const float fa = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(sa[l])));
-            const uint32_t fpair = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)pair);
-            const float xf = floorf(fx), yf = floorf(fy);
-            const float lw = fx - xf, lh = fy - yf, hw = 1.f - lw, hh = 1.f - lh;
-            const int x0 = (int)xf, y0 = (int)yf;              // in range: -1 <= x0 < W, -1 <= y0 < H
-            const bool t_ok = act & (y0 >= 0), b_ok = act & (y0 + 1 <= Hl - 1), l_ok = x0 >= 0, r_ok = x0 + 1 <= Wl - 1;
-            const uint32_t p00 = (uint32_t)(Sl + y0 * Wl + x0) * pixB + (uint32_t)ch * 4u;   // (garbage where the corner is dead: masked)
-            const uint32_t rowG = (uint32_t)Wl * pixB;
-            const uint32_t o1 = (t_ok & l_ok) ? p00 : kOobOffset, o2 = (t_ok & r_ok) ? p00 + pixB : kOobOffset;
-            const uint32_t o3 = (b_ok & l_ok) ? p00 + rowG : kOobOffset, o4 = (b_ok & r_ok) ? p00 + rowG + pixB : kOobOffset;
-            const float v1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(vsrc, o1, hoff, 0));
-            const float v2 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(vsrc, o2, hoff, 0));
-            const float v3 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(vsrc, o3, hoff, 0));
-            const float v4 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(vsrc, o4, hoff, 0));
-            const float g = act ? grad_out[pair_img * 32 + fpair * 32u + (uint32_t)ch] : 0.f;
-            const float tt = v2 - v1, tb = v4 - v3;
-            const float top = fmaf(lw, tt, v1), bot = fmaf(lw, tb, v3);
-            const float dd = bot - top;
-            const float val = fmaf(lh, dd, top), dx = fmaf(lh, tb, hh * tt);
-            const float ra = half_sum(g * val), rw = half_sum(g * dx) * fa * (float)Wl, rh = half_sum(g * dd) * fa * (float)Hl;
-            // the owners keep their sample's three gradients (every lane of a half holds that half's totals)
-            const float raA = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ra), 0)), raB = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ra), 32));
-            const float rwA = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rw), 0)), rwB = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rw), 32));
-            const float rhA = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rh), 0)), rhB = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rh), 32));
-            if (ln == sA) { ga[l] = raA; glx[l] = rwA; gly[l] = rhA; }
-            if (hasB && ln == sB) { ga[l] = raB; glx[l] = rwB; gly[l] = rhB; }
-            // grad_value: w_corner * a * g_c, one full-line float atomic per live corner
-            const float tg = g * fa;
-            if (o1 != kOobOffset) atomic_add(reinterpret_cast<float*>(gv_head + o1), hh * hw * tg);
-            if (o2 != kOobOffset) atomic_add(reinterpret_cast<float*>(gv_head + o2), hh * lw * tg);
-            if (o3 != kOobOffset) atomic_add(reinterpret_cast<float*>(gv_head + o3), lh * hw * tg);
-            if (o4 != kOobOffset) atomic_add(reinterpret_cast<float*>(gv_head + o4), lh * lw * tg);
-          }
-        }
-      }
       BW_STAMP(7);                                           // classified, far samples done
       if (pass == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of the value windows has landed
@@ -594,6 +527,76 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
 
       __builtin_amdgcn_s_setprio(0);
       BW_STAMP(10);                                          // pass done
+      // ---- far samples, BEHIND the pass: they need no window, and a wave that is through its pass early does them while the others
+      // are still in theirs (in front of barrier #3 their imbalance was waited for by everybody: 281 -> ... us) -- a HALF of the wave
+      // per sample (lane = channel), two samples per iteration; the corner loads of an
+      // iteration are all in flight before anything waits for them ------------------------------------------------------------
+      {
+        const uint32_t farbits = inb & ~nb;
+        const int ch = ln & 31;
+        // over the 32 lanes of a half; every lane gets the total: four DPP butterfly steps inside a row of 16 lanes and ONE
+        // cross-row exchange (as a shuffle loop it was a chain of five dependent ds_bpermute round trips per value).
+        // (Tried and dropped: software-pipelining this loop -- the next iteration's loads issued before this one's are
+        // waited for -- changed nothing, 342.6 vs 342 us and 1145 vs 1139 us on the wide flavour: the loop is bound by its
+        // four full-line atomics per sample, not by the round trips of its loads.)
+        auto half_sum = [](float v) __attribute__((always_inline)) {
+          v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+          v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+          v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+          v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));   // row_mirror
+          v += __shfl_xor(v, 16, 64);
+          return v;
+        };
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+          uint64_t fm = __ballot(((farbits >> l) & 1u) != 0u);
+          const int Hl = lvH[l], Wl = lvW[l], Sl = lvS[l];
+          while (fm) {
+            const int sA = __builtin_ctzll(fm);
+            fm &= fm - 1;
+            const bool hasB = fm != 0;
+            const int sB = hasB ? __builtin_ctzll(fm) : sA;
+            if (hasB) fm &= fm - 1;
+            const bool act = (ln < 32) | hasB;
+            const int src = (ln < 32 ? sA : sB) << 2;
+            const float fx = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(xy[l].x)));
+            const float fy = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(xy[l].y)));
+            const float fa = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(sa[l])));
+            const uint32_t fpair = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)pair);
+            const float xf = floorf(fx), yf = floorf(fy);
+            const float lw = fx - xf, lh = fy - yf, hw = 1.f - lw, hh = 1.f - lh;
+            const int x0 = (int)xf, y0 = (int)yf;              // in range: -1 <= x0 < W, -1 <= y0 < H
+            const bool t_ok = act & (y0 >= 0), b_ok = act & (y0 + 1 <= Hl - 1), l_ok = x0 >= 0, r_ok = x0 + 1 <= Wl - 1;
+            const uint32_t p00 = (uint32_t)(Sl + y0 * Wl + x0) * pixB + (uint32_t)ch * 4u;   // (garbage where the corner is dead: masked)
+            const uint32_t rowG = (uint32_t)Wl * pixB;
+            const uint32_t o1 = (t_ok & l_ok) ? p00 : kOobOffset, o2 = (t_ok & r_ok) ? p00 + pixB : kOobOffset;
+            const uint32_t o3 = (b_ok & l_ok) ? p00 + rowG : kOobOffset, o4 = (b_ok & r_ok) ? p00 + rowG + pixB : kOobOffset;
+            const float v1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(vsrc, o1, hoff, 0));
+            const float v2 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(vsrc, o2, hoff, 0));
+            const float v3 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(vsrc, o3, hoff, 0));
+            const float v4 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(vsrc, o4, hoff, 0));
+            const float g = act ? grad_out[pair_img * 32 + fpair * 32u + (uint32_t)ch] : 0.f;
+            const float tt = v2 - v1, tb = v4 - v3;
+            const float top = fmaf(lw, tt, v1), bot = fmaf(lw, tb, v3);
+            const float dd = bot - top;
+            const float val = fmaf(lh, dd, top), dx = fmaf(lh, tb, hh * tt);
+            const float ra = half_sum(g * val), rw = half_sum(g * dx) * fa * (float)Wl, rh = half_sum(g * dd) * fa * (float)Hl;
+            // the owners keep their sample's three gradients (every lane of a half holds that half's totals)
+            const float raA = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ra), 0)), raB = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ra), 32));
+            const float rwA = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rw), 0)), rwB = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rw), 32));
+            const float rhA = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rh), 0)), rhB = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rh), 32));
+            if (ln == sA) { ga[l] = raA; glx[l] = rwA; gly[l] = rhA; }
+            if (hasB && ln == sB) { ga[l] = raB; glx[l] = rwB; gly[l] = rhB; }
+            // grad_value: w_corner * a * g_c, one full-line float atomic per live corner
+            const float tg = g * fa;
+            if (o1 != kOobOffset) atomic_add(reinterpret_cast<float*>(gv_head + o1), hh * hw * tg);
+            if (o2 != kOobOffset) atomic_add(reinterpret_cast<float*>(gv_head + o2), hh * lw * tg);
+            if (o3 != kOobOffset) atomic_add(reinterpret_cast<float*>(gv_head + o3), lh * hw * tg);
+            if (o4 != kOobOffset) atomic_add(reinterpret_cast<float*>(gv_head + o4), lh * lw * tg);
+          }
+        }
+      }
+
       // ---- this lane's point on the four levels: grad_attn_weight, grad_sampling_loc --------------------------------------
       if (live) {
         float* gap = grad_attn + pair_img * 16 + (pair * 16u + (uint32_t)k);
