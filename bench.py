@@ -181,6 +181,18 @@ def committed_traffic(kernel, which="forward_encoder"):
 def time_events(fn, reps, pre=None):
     """Mean duration (us) of fn() over `reps` launches, each bracketed by its own pair of HIP events on the current
     stream; `pre` runs outside the events (e.g. zeroing the accumulation target)."""
+    # by TIME first: the host-side set-up in front of every extra leaves the device idle long enough for its clock to drop,
+    # and the first launches after that run 10-15 % slower (round 3: 343 us for a kernel tools/kbench.py had at 300)
+    t_w = time.perf_counter()
+    n_w = 0
+    while (time.perf_counter() - t_w) * 1e3 < EXTRA_WARM_MS:
+        if pre is not None:
+            pre()
+        fn()
+        n_w += 1
+        if n_w % 4 == 0:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
     evs = []
     for _ in range(reps):
         if pre is not None:
@@ -249,6 +261,7 @@ def measure_forward_kernels(enc, reps=12):
 
 
 EVENT_EVERY = 4      # steps of the timed region whose encoder launches are bracketed by HIP events
+EXTRA_WARM_MS = 60.0  # untimed launches in front of every extra leg's timed launches
 PREWARM_MS = 150.0   # untimed launches before the W warm-up steps (device clocks)
 BWD_SITE = 30   # call site of measure_backward's encoder calls (forward and backward, as a module's are)
 
@@ -330,10 +343,13 @@ def train_step_fn(enc, dec):
     return step
 
 
-def measure_train_step(enc, dec, world, reps=5):
+def measure_train_step(enc, dec, world, reps=10):
     step = train_step_fn(enc, dec)
-    for _ in range(4):                                  # (the call sites' first locality reports are consumed two calls later)
-        step()
+    t_w = time.perf_counter()
+    n_w = 0
+    while n_w < 4 or (time.perf_counter() - t_w) * 1e3 < EXTRA_WARM_MS:   # (>= 4: the call sites' first locality reports are
+        step()                                                              # consumed two calls later; by time: device clocks)
+        n_w += 1
     barrier(world)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
