@@ -38,9 +38,10 @@
 // trees of exec-masked branches; 24-bit multiply-adds are inline asm (v_mad_u32_u24) -- __mul24 comes back as quarter-rate
 // v_mul_lo_u32; quotients use v_rcp_f32; (query, head) pair indices are 32-bit below uniform per-image base pointers.
 //
-// All geometry comes from the int64 shape tensors on the device; the host only knows S, so the grid has
-// ceil(S / 128) workgroups per (image, head) -- at least the number of tiles of any pyramid whose level 0 holds
-// <= ~3/4 of the pixels -- and a workgroup walks tiles g, g + G, ... (one tile, or none, at the R50 shapes).
+// All geometry comes from the int64 shape tensors on the device; the host only knows S.  The grid is persistent: the two
+// workgroups a CU holds walk the items kk, kk + K, ... of their head (win_workgroups_per_head below; 4-5 items each at the
+// R50 shapes).
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -906,6 +907,28 @@ bool begin_stat_launch(LocalityArgs* la, hipEvent_t* ev) {
 }
 }  // namespace
 
+// Workgroups per head (grid y; head m = blockIdx.x of the 2-D grid, i.e. -- by the observed round-robin placement of the linear
+// workgroup id -- XCD m % 8 only ever touches head m's slice of `value`).  Persistent: the two workgroups a CU can hold (79 KB
+// of LDS each) walk the items kk, kk + K, ... of their head -- 74.4 against 77.5 us per launch in the bench step, 70-72 against
+// 73 us back to back, three A/B rounds each on one box (profiles/r03_forward_window_analysis.txt section 9; what the one-shot
+// grid pays is a kernel prologue per item -- NOT dispatch time, a freed slot is refilled within 0.3 us, and NOT the partial
+// last turn of the items, which neither a largest-first order nor splitting its items shortened).  The one-shot count -- a
+// call with fewer items than that, or MSDA_WIN_PERSIST=0 -- is ceil(S / 128) per image, all the host knows: at least the tile
+// count of any pyramid whose level 0 holds <= ~3/4 of the pixels; surplus workgroups exit at once.
+static int win_workgroups_per_head(const Dims& d) {
+  static const bool oneshot = std::getenv("MSDA_WIN_PERSIST") && std::getenv("MSDA_WIN_PERSIST")[0] == '0';   // A/B switch
+  static const int cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  int K = d.N * ((d.S + 127) / 128);
+  if (!oneshot) K = std::min(K, std::max(1, (2 * cus) / std::max(d.M, 1)));
+  if (K < 1) K = 1;
+  if (K > 65535) K = 65535;                                 // (grid y extent; a workgroup walks units kk, kk + K, ...)
+  return K;
+}
+
 int launch_forward_win(const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc, const float* attn,
                        const Dims& d, float* out, hipStream_t stream) {
   static const bool nt = std::getenv("MSDA_WIN_NT") && std::getenv("MSDA_WIN_NT")[0] == '1';   // A/B switch
@@ -916,16 +939,7 @@ int launch_forward_win(const float* value, const int64_t* shapes, const int64_t*
   const auto kern = stat ? (nt ? msda_fwd_win<2, true> : msda_fwd_win<0, true>) : msda_fwd_win<0, false>;
   const void* fn = reinterpret_cast<const void*>(kern);
   if (int rc = ensure_dynamic_lds(fn, kLdsBytes, lds_opted_in[stat ? (nt ? 1 : 0) : 2])) return rc;
-  // Workgroups per head.  Default: one work item per workgroup -- the host only knows S, so ceil(S / 128) per image,
-  // at least the tile count of any pyramid whose level 0 holds <= ~3/4 of the pixels; the surplus exits at once and the
-  // dispatcher staggers the rest, which keeps the memory / LDS / VALU phases of neighbouring workgroups out of step.
-  // MSDA_WIN_PERSIST=1: two resident workgroups per CU walk the items (measured slower: every workgroup of the chip
-  // enters the same phase at the same time).  Either way head m = blockIdx.x of a 2-D grid, i.e. (by the observed round-robin
-  // placement) XCD m only ever touches head m's slice of `value`.
-  static const bool persist = std::getenv("MSDA_WIN_PERSIST") && std::getenv("MSDA_WIN_PERSIST")[0] == '1';
-  int K = persist ? (2 * 256) / d.M : d.N * ((d.S + 127) / 128);
-  if (K < 1) K = 1;
-  if (K > 65535) K = 65535;                                 // (grid y extent; a workgroup then walks items kk, kk + K, ...)
+  const int K = win_workgroups_per_head(d);
   const dim3 grid((unsigned)d.M, (unsigned)K);
   hipLaunchKernelGGL(kern, grid, dim3(kT), kLdsBytes, stream, value, shapes, lsi, loc, attn, d, out, la);
   const int rc = (int)hipGetLastError();
@@ -944,9 +958,7 @@ int launch_forward_win_fused(const float* value, int head_major, const int64_t* 
                                  : (stat ? msda_fwd_win_fused<true, 4> : msda_fwd_win_fused<false, 4>);
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), kLdsBytes, lds_opted_in[(ref_dim == 2 ? 0 : 2) + (stat ? 1 : 0)]))
     return rc;
-  int K = d.N * ((d.S + 127) / 128);                        // as in launch_forward_win
-  if (K < 1) K = 1;
-  if (K > 65535) K = 65535;
+  const int K = win_workgroups_per_head(d);
   hipLaunchKernelGGL(kern, dim3((unsigned)d.M, (unsigned)K), dim3(kT), kLdsBytes, stream, value, head_major, shapes, lsi,
                      ref_points, offsets, logits, d, out, la);
   const int rc = (int)hipGetLastError();
