@@ -89,9 +89,10 @@ int msda_hip_forward_f64(const double* value, const int64_t* spatial_shapes,
  * plain fp32 in every kernel.  tests/test_msda_parity_gpu.py holds the bound on inputs with 8 decades of dynamic range.
  * The same holds for msda_bwd_win (encoder-shaped calls of a call site with near samples) and, on the rows of the two
  * coarsest levels it keeps in LDS, for msda_bwd_dec -- variant 0 on every other fp32 call with channels 32, 4 levels x 4
- * points and >= 64 queries (the decoder): one scale per (image, head, slice of <= ceil(num_query / 16) queries) from
- * (4 * queries of the slice) * max|grad_output| * max|attn_weight|, i.e. steps of <= 2^-21 * max|grad_output| of the
- * slice for num_query <= 2048.  The finer levels take float atomics there as in the reference.
+ * points and 64 .. 16384 queries (the decoder): one scale per (image, head, slice of <= min(ceil(num_query / 16), 256)
+ * queries) from (4 * queries of the slice) * max|grad_output| * max|attn_weight|, i.e. steps of <= 2^-20 * max|grad_output|
+ * of the slice (<= 2^-21 for num_query <= 2048).  The finer levels take float atomics there as in the reference; calls with
+ * more queries than that (and not encoder-shaped) take msda_bwd_generic, float atomics throughout.
  */
 int msda_hip_backward_f32(const float* grad_output, const float* value,
                           const int64_t* spatial_shapes, const int64_t* level_start_index,

@@ -600,6 +600,33 @@ def test_decoder_backward_kernel_on_other_pyramids_and_query_counts(levels, num_
         assert float(d_gl[:, :, :, l].max()) < 1e-4 * max(h, w, 10), (l, float(d_gl[:, :, :, l].max()))
 
 
+def test_decoder_backward_kernel_bounds_the_queries_of_a_slice(dev, api):
+    """The fixed-point step of msda_bwd_dec rests on <= 256 queries per (image, head, slice): a call with more than 16 x 256
+    queries gets more slices (every element against the oracle), one with more than 64 x 256 takes msda_bwd_generic even when
+    the variant is forced."""
+    from oracle import msda_oracle
+    from uninext_amd import workloads
+    MSDA, lib = api
+    levels = ((64, 80), (32, 40), (16, 20), (8, 10))
+    x = workloads.make_inputs("decoder", "model", batch=2, levels=levels, num_query=5000, heads=4, seed=85, device=dev)
+    go = torch.randn(2, 5000, 128, generator=torch.Generator().manual_seed(86)).to(dev)
+    gv, gl, ga = _bwd(MSDA, lib, x, go, "msda_bwd_dec")
+    assert lib.last_kernel("backward") == "msda_bwd_dec"
+    tgv, tgl, tga = msda_oracle.backward(go.double(), x["value"].double(), x["shapes"], x["lsi"], x["loc"].double(), x["attn"].double())
+    _, _, oga = msda_oracle.backward(go, x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
+    # 250 adds per pixel of the coarsest level (80 pixels for 20 000 samples), each rounded to the slice's step
+    assert float(np.abs(gv.cpu().numpy().astype(np.float64) - tgv).max()) < 2e-4
+    e_ga, o_ga = float(np.abs(ga.cpu().numpy().astype(np.float64) - tga).max()), float(np.abs(oga - tga).max())
+    assert e_ga < max(1e-4, 2.0 * o_ga), (e_ga, o_ga)      # (32-term dot products of magnitude ~7: the fp32 oracle is the yardstick)
+    assert float(np.abs(gl.cpu().numpy().astype(np.float64) - tgl).max()) < 1e-4 * 80
+    x = workloads.make_inputs("decoder", "model", batch=1, levels=levels, num_query=16385, heads=2, seed=87, device=dev)
+    go = torch.randn(1, 16385, 64, generator=torch.Generator().manual_seed(88)).to(dev)
+    gv, _, _ = _bwd(MSDA, lib, x, go, "msda_bwd_dec")
+    assert lib.last_kernel("backward") == "msda_bwd_generic"
+    tgv, _, _ = msda_oracle.backward(go.double(), x["value"].double(), x["shapes"], x["lsi"], x["loc"].double(), x["attn"].double())
+    assert float(np.abs(gv.cpu().numpy().astype(np.float64) - tgv).max()) < 2e-4   # ~100 float atomics per coarse pixel
+
+
 def test_decoder_backward_fixed_point_bound_and_non_finite_inputs(dev, api):
     """The LDS accumulators of msda_bwd_dec are fixed point with a per-workgroup scale from (#queries of the slice x 4) x
     max |grad_out| x max |attn|: upstream gradients with 8 decades of dynamic range stay within the documented step of the

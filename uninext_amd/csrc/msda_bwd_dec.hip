@@ -9,6 +9,7 @@
 // overflow, as msda_bwd_tiled), and every touched accumulator row leaves once, as one full-line float atomic.  Levels 0
 // and 1 (and rows that did not fit) take the direct atomics of msda_bwd_generic; grad_sampling_loc / grad_attn_weight
 // are computed as there (half a wave per pair, lane = channel, DPP sums), every element written once.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 
@@ -168,8 +169,25 @@ msda_bwd_dec(const float* __restrict__ grad_out, const float* __restrict__ value
   }
 }
 
+// Slices of the queries per (image, head): enough workgroups to cover the chip once, at most 16 (every slice flushes its own
+// accumulators) -- and at most kDecSliceQueries queries per slice, which is what the documented step of the fixed-point
+// accumulators rests on (include/msda_hip.h: the scale of a slice comes from 4 x its queries x max |grad_out| x max |attn|; a
+// coarse level's pixel collects a rounding per add, and thousands of queries per slice would push their sum past 1e-4).
+// MSDA_BWD_DEC_SLICES=n: A/B switch for the first rule.
+constexpr int kDecSliceQueries = 256, kDecMaxSlices = 64;
+static int dec_slices(const Dims& d) {
+  static const int env = std::getenv("MSDA_BWD_DEC_SLICES") ? std::atoi(std::getenv("MSDA_BWD_DEC_SLICES")) : 0;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const int64_t heads = std::max<int64_t>(1, (int64_t)d.M * d.N);
+  int nsl = env > 0 ? env : (int)std::min<int64_t>(16, (cus + heads - 1) / heads);
+  nsl = std::max(1, std::min(nsl, 16));
+  nsl = std::min(nsl, (d.Lq + 31) / 32);
+  return std::max(nsl, (d.Lq + kDecSliceQueries - 1) / kDecSliceQueries);
+}
+
 bool dec_backward_ok(const Dims& d) {
-  return d.D == 32 && d.L == 4 && d.P == 4 && d.Lq >= 64 && d.M <= 65535 && d.N <= 65535;
+  return d.D == 32 && d.L == 4 && d.P == 4 && d.Lq >= 64 && d.M <= 65535 && d.N <= 65535 && dec_slices(d) <= kDecMaxSlices;
 }
 
 int launch_backward_dec(const float* grad_out, const float* value, const int64_t* shapes, const int64_t* lsi,
@@ -177,14 +195,7 @@ int launch_backward_dec(const float* grad_out, const float* value, const int64_t
                         float* grad_attn, hipStream_t stream) {
   static std::atomic<uint64_t> lds_opted_in{0};
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(msda_bwd_dec), kDecLds, lds_opted_in)) return rc;
-  // slices of the queries per (image, head): enough workgroups to cover the chip once, at most 16 (every slice flushes its own
-  // accumulators).  MSDA_BWD_DEC_SLICES=n: A/B switch.
-  static const int env = std::getenv("MSDA_BWD_DEC_SLICES") ? std::atoi(std::getenv("MSDA_BWD_DEC_SLICES")) : 0;
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  int nsl = env > 0 ? env : (cus + d.M * d.N - 1) / (d.M * d.N);
-  nsl = std::max(1, std::min(nsl, 16));
-  nsl = std::min(nsl, (d.Lq + 31) / 32);
+  const int nsl = dec_slices(d);
   hipLaunchKernelGGL(msda_bwd_dec, dim3((unsigned)d.M, (unsigned)nsl, (unsigned)d.N), dim3(kDT), kDecLds, stream, grad_out, value,
                      shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn);
   return (int)hipGetLastError();
