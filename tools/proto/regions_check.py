@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Development check of msda_bwd_regions against the C oracle (GPU box):
-    python tools/regions_check.py [--quick] [--time]
+    python tools/proto/regions_check.py [--quick] [--time]
 Every element of grad_value / grad_sampling_loc / grad_attn_weight on small and odd pyramids and at the full R50 size in the
 three location flavours, two calls in a row (the workspace must come back clean), grad_loc / grad_attn bitwise against
 msda_bwd_tiled (the same query-side pass); on a mismatch, where the wrong pixels are.  MSDA_BWD_REGIONS_HIST=8 runs the file
@@ -12,7 +12,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import msda_oracle  # noqa: E402
 from uninext_amd import _lib, ext, workloads  # noqa: E402

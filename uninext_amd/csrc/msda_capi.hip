@@ -19,7 +19,7 @@ std::atomic<int> g_variant[2] = {{-1}, {-1}};  // -1: not initialised (read env 
 
 const char* const kVariantNames[2][msda::kNumVariants] = {
     {"auto", "msda_fwd_generic", "msda_fwd_lanegroup", "msda_fwd_tiled", "msda_fwd_tiled_l0", "msda_fwd_tiled_l0big", "msda_fwd_lgcl", "msda_fwd_lg3", "msda_fwd_lgp", "msda_fwd_win", "msda_fwd_win2", "msda_fwd_win3", "msda_fwd_win4"},
-    {"auto", "msda_bwd_generic", "msda_bwd_lanegroup", "msda_bwd_tiled", "msda_bwd_win", "msda_bwd_dec", "msda_bwd_regions", "msda_bwd_tiled", "msda_bwd_tiled", "msda_bwd_tiled", "msda_bwd_tiled", "msda_bwd_tiled", "msda_bwd_tiled"},
+    {"auto", "msda_bwd_generic", "msda_bwd_lanegroup", "msda_bwd_tiled", "msda_bwd_win", "msda_bwd_dec", "msda_bwd_tiled", "msda_bwd_tiled", "msda_bwd_tiled", "msda_bwd_tiled", "msda_bwd_tiled", "msda_bwd_tiled", "msda_bwd_tiled"},
 };
 
 int current_variant(int which) {

@@ -300,6 +300,7 @@ struct Workspace {
   std::mutex mu;
   char* buf = nullptr;
   size_t bytes = 0;
+  size_t table_bytes = 0;          // capacity of each of the three bin tables; the layout depends on the CAPACITY, never on the call
   hipEvent_t done = nullptr;
   hipStream_t last = nullptr;
   bool used = false;
@@ -336,29 +337,33 @@ int launch_backward_regions(const float* grad_out, const float* value, const int
   // bins <= N * M * S (a region holds at least one pixel); records <= 4 per sample
   const size_t max_bins = (size_t)d.N * d.M * d.S + 1;
   const size_t b_counts = align256(max_bins * 4), b_recs = align256((size_t)d.N * d.Lq * d.M * 16 * 4 * sizeof(Rec));
-  const size_t need = 3 * b_counts + b_recs;
   Workspace& ws = g_ws[dev];
   std::lock_guard<std::mutex> lock(ws.mu);
   if (!ws.done && hipEventCreateWithFlags(&ws.done, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
-  if (ws.bytes < need) {
+  // The tables sit at offsets that depend on the workspace's CAPACITY (a first version laid them out by the CALL's sizes: a
+  // smaller call after a larger one then found its `counts` inside the larger call's tables, not zero, and its records went
+  // wherever the garbage starts pointed -- found by the named-workload suite, which changes shapes from test to test).
+  if (ws.table_bytes < b_counts || ws.bytes < 3 * ws.table_bytes + b_recs) {
+    const size_t tb = std::max(ws.table_bytes, b_counts), rb = std::max(ws.bytes > 3 * ws.table_bytes ? ws.bytes - 3 * ws.table_bytes : 0, b_recs);
     if (ws.buf) {
       if (hipError_t e = hipDeviceSynchronize(); e != hipSuccess) return (int)e;   // (grows a few times per process at most)
       (void)hipFree(ws.buf);
       ws.buf = nullptr;
-      ws.bytes = 0;
+      ws.bytes = ws.table_bytes = 0;
     }
-    if (hipError_t e = hipMalloc(reinterpret_cast<void**>(&ws.buf), need); e != hipSuccess) return (int)e;
-    ws.bytes = need;
+    if (hipError_t e = hipMalloc(reinterpret_cast<void**>(&ws.buf), 3 * tb + rb); e != hipSuccess) return (int)e;
+    ws.bytes = 3 * tb + rb;
+    ws.table_bytes = tb;
     ws.used = false;
-    // counts and cursors start at zero; every call leaves them so (msda_bwd_regions_scan)
-    if (hipError_t e = hipMemsetAsync(ws.buf, 0, need - b_recs, stream); e != hipSuccess) return (int)e;
   } else if (ws.used && ws.last != stream) {
     if (hipError_t e = hipStreamWaitEvent(stream, ws.done, 0); e != hipSuccess) return (int)e;
   }
   uint32_t* const counts = reinterpret_cast<uint32_t*>(ws.buf);
-  uint32_t* const starts = reinterpret_cast<uint32_t*>(ws.buf + b_counts);
-  uint32_t* const cursors = reinterpret_cast<uint32_t*>(ws.buf + 2 * b_counts);
-  Rec* const recs = reinterpret_cast<Rec*>(ws.buf + 3 * b_counts);
+  uint32_t* const starts = reinterpret_cast<uint32_t*>(ws.buf + ws.table_bytes);
+  uint32_t* const cursors = reinterpret_cast<uint32_t*>(ws.buf + 2 * ws.table_bytes);
+  Rec* const recs = reinterpret_cast<Rec*>(ws.buf + 3 * ws.table_bytes);
+  // counts of this call's bins start at zero whatever an earlier (possibly aborted) call left: 1.4 MB, ~2 us
+  if (hipError_t e = hipMemsetAsync(counts, 0, b_counts, stream); e != hipSuccess) return (int)e;
 
   if (int rc = launch_backward_tiled_nogv(grad_out, value, shapes, lsi, loc, attn, d, grad_loc, grad_attn, stream)) return rc;
   const dim3 fgrid((unsigned)((d.Lq + kRT - 1) / kRT), (unsigned)d.M, (unsigned)d.N);
