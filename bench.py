@@ -319,6 +319,32 @@ def measure_backward(enc, dec, reps=10):
                      "note": "launch only; the grad_value memset (N*S*1024 B) is outside the events"
                              + ("; the calls carry the context of a call site whose forward calls ran first, as a module's backward does" if site >= 0 else "")}
         del sets
+    # the encoder backward on the other two location flavours (training shapes): the backward of a call site whose forward calls
+    # have reported far samples takes msda_bwd_regions (include/msda_hip.h)
+    fl_out = {}
+    for idx, fl in enumerate(("uniform", "wide")):
+        site = BWD_SITE + 1 + idx
+        sets = []
+        for i in range(2):
+            x = workloads.make_workload("r50_train_encoder", fl, seed=980 + 10 * idx + i, device="cuda")
+            go = torch.randn(x["value"].shape[0], x["loc"].shape[1], 256, generator=torch.Generator().manual_seed(990 + i)).cuda()
+            sets.append((x, go, torch.zeros_like(x["value"]), torch.empty_like(x["loc"]), torch.empty_like(x["attn"])))
+        for _ in range(4):
+            for s_ in sets:
+                call(s_[0], site)
+        for s_ in sets:
+            backward_call(*s_, site=site)
+        k = [0]
+
+        def pre():
+            k[0] += 1
+            sets[k[0] % len(sets)][2].zero_()
+
+        def one():
+            backward_call(*sets[k[0] % len(sets)], site=site)
+        fl_out[fl] = {"launch_us": time_events(one, reps, pre), "kernel": _lib.last_kernel("backward")}
+        del sets
+    out["encoder_flavours"] = fl_out
     return out
 
 

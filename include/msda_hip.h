@@ -93,6 +93,9 @@ int msda_hip_forward_f64(const double* value, const int64_t* spatial_shapes,
  * queries) from (4 * queries of the slice) * max|grad_output| * max|attn_weight|, i.e. steps of <= 2^-20 * max|grad_output|
  * of the slice (<= 2^-21 for num_query <= 2048).  The finer levels take float atomics there as in the reference; calls with
  * more queries than that (and not encoder-shaped) take msda_bwd_generic, float atomics throughout.
+ * msda_bwd_regions (backward variant 6) has no fixed point: every pixel's corners are added in float64 by the one workgroup
+ * that owns the pixel and rounded to float ONCE (each term is the float product weight x attention x grad_output as in the
+ * reference); its grad_value differs from the exact sum by one float rounding.
  */
 int msda_hip_backward_f32(const float* grad_output, const float* value,
                           const int64_t* spatial_shapes, const int64_t* level_start_index,
@@ -168,6 +171,11 @@ int msda_host_backward_f64(const double* grad_output, const double* value, const
                            int num_point, double* grad_value, double* grad_sampling_loc, double* grad_attn_weight,
                            int num_threads);
 
+/* Host threads the last msda_host_* call of the calling thread actually ran on (diagnostic; 0 before any call).  With
+ * num_threads <= 0 that is min(hardware threads, independent units, one per ~256 rows of work): rows = batch * num_query
+ * for the forward, (image, head) slices of num_query rows each for the backward. */
+int msda_host_last_num_threads(void);
+
 /*
  * Kernel selection (tuning / A-B measurement only; results are identical up to fp32
  * summation order).  which: 0 = forward, 1 = backward.  variant: 0 = automatic (default),
@@ -213,8 +221,12 @@ const char* msda_hip_last_kernel(int which);
  *
  * Backward (variant 0, fp32, encoder shape): msda_bwd_win -- value and gradient windows in LDS -- when the call carries a
  * context (geometry vouched for, not deterministic) and the FORWARD calls of that call site have last reported a far
- * fraction <= 0.05; msda_bwd_tiled otherwise (no context, no forward yet, samples not near).  A backward call launches
- * no report and waits for nothing: its choice follows the call sequence of the site's forward calls.
+ * fraction <= 0.05; msda_bwd_regions -- grad_value summed on the destination side, no global atomics, time independent of
+ * the locations -- when they have last reported one >= 0.30; msda_bwd_tiled otherwise (no context, no forward yet, in
+ * between).  A backward call launches no report and waits for nothing: its choice follows the call sequence of the site's
+ * forward calls.  msda_bwd_regions keeps a per-device workspace (bin tables + up to four 32-byte records per sample, ~0.7 GB
+ * at the R50 training shapes, allocated at its first call, handed from stream to stream behind an event; inside a stream
+ * capture the call takes msda_bwd_tiled instead).
  *
  * msda_hip_forward_locality: number of reports consumed so far on the call site used last on the current device (it
  * waits for the launches made so far on that site) and, in *far_fraction (may be NULL), the far fraction of the latest.

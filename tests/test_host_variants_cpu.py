@@ -86,6 +86,29 @@ def test_thread_count_does_not_change_the_result(monkeypatch):
             assert torch.equal(a, b)    # one thread per (image, head) slice of grad_value: bitwise deterministic
 
 
+def test_default_thread_count_follows_the_work_not_the_number_of_slices(monkeypatch):
+    """the backward's units are (image, head) slices of num_query rows each; 16 slices must not mean one thread."""
+    import os
+    from uninext_amd import _lib, ext, workloads
+    lib = _lib.load()
+    hw = os.cpu_count() or 1
+    if hw < 2:
+        pytest.skip("one hardware thread")
+    x = workloads.make_inputs("encoder", "model", batch=2, levels=((25, 42), (13, 21), (7, 11), (4, 6)), seed=8, device="cpu")
+    Lq = x["loc"].shape[1]
+    go = torch.randn(2, Lq, 256, generator=torch.Generator().manual_seed(1))
+    monkeypatch.setattr(ext, "HOST_THREADS", 0)
+    ext.ms_deform_attn_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], 64)
+    assert lib.msda_host_last_num_threads() == min(hw, max(1, 2 * Lq // 256))
+    ext.ms_deform_attn_backward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], go, 64)
+    # 2 images x 8 heads = 16 slices of 1400 rows: min(hardware threads, 16 slices, 16 * 1400 / 256 rows of work)
+    assert lib.msda_host_last_num_threads() == min(hw, 16)
+    # a tiny call still gets one thread
+    y = workloads.make_inputs("decoder", "model", batch=1, levels=((9, 11), (5, 6)), num_query=20, seed=8, device="cpu")
+    ext.ms_deform_attn_backward(y["value"], y["shapes"], y["lsi"], y["loc"], y["attn"], torch.randn(1, 20, 256), 64)
+    assert lib.msda_host_last_num_threads() == 1
+
+
 def test_autograd_function_and_gradcheck_on_cpu():
     """ops/test.py:60-76 (check_gradient_numerical) on the host variants."""
     from uninext_amd.functions import MSDeformAttnFunction
@@ -144,7 +167,7 @@ def test_host_variants_reject_levels_outside_the_value_tensor():
     attn = torch.softmax(torch.randn(1, 3, 2, 4), -1).view(1, 3, 2, 2, 2)
     ok = ext.ms_deform_attn_forward(value, shapes, torch.tensor([0, 16], dtype=torch.int64), loc, attn, 64)
     assert ok.shape == (1, 3, 8)
-    for bad_lsi in ([0, 17], [-1, 16], [0, 1 << 40]):
+    for bad_lsi in ([0, 17], [-1, 16], [0, 1 << 40], [0, (1 << 63) - 1], [0, (1 << 63) - 3]):   # (start + H * W would wrap)
         with pytest.raises(RuntimeError):
             ext.ms_deform_attn_forward(value, shapes, torch.tensor(bad_lsi, dtype=torch.int64), loc, attn, 64)
         with pytest.raises(RuntimeError):

@@ -364,7 +364,7 @@ def test_full_size_encoder_backward(levels, variant, dev, api):
         gv, gl, ga = MSDA.ms_deform_attn_backward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], go, 64)
     finally:
         lib.set_variant("backward", "auto")
-    assert lib.last_kernel("backward") in (("msda_bwd_tiled", "msda_bwd_win") if variant == "auto" else (variant,))
+    assert lib.last_kernel("backward") in (("msda_bwd_tiled", "msda_bwd_win", "msda_bwd_regions") if variant == "auto" else (variant,))
     # per-query gradients: oracle on a query subset
     idx = torch.cat([torch.arange(0, 200), torch.arange(S - 200, S),
                      torch.randint(0, S, (400,), generator=torch.Generator().manual_seed(2))]).to(dev)

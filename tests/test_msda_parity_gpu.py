@@ -54,7 +54,7 @@ def _inputs(flavour, levels, seed, dev):
     return workloads.make_inputs("encoder", batch=2, levels=levels, seed=seed, device=dev, **kw)
 
 
-ENCODER_BWD = ("msda_bwd_tiled", "msda_bwd_win")     # what variant "auto" may take on an encoder-shaped fp32 call
+ENCODER_BWD = ("msda_bwd_tiled", "msda_bwd_win", "msda_bwd_regions")     # what variant "auto" may take on an encoder-shaped fp32 call
 
 
 def _bwd(MSDA, lib, x, go, variant):
@@ -282,8 +282,8 @@ def test_window_backward_on_odd_pyramids(levels, flavour, dev, api):
 
 def test_backward_choice_follows_the_forward_reports_of_its_call_site(dev, api):
     """include/msda_hip.h: variant 0 backward on the encoder shape takes msda_bwd_win when the forward calls of the SAME call
-    site have reported near samples, msda_bwd_tiled otherwise -- no forward yet on the site, far samples, no context
-    (deterministic mode), or another site's reports."""
+    site have reported near samples, msda_bwd_regions when they have reported far ones, msda_bwd_tiled otherwise -- no context
+    (deterministic mode), no report yet; another site's reports do not count."""
     from uninext_amd import ext, workloads
     MSDA, lib = api
     near = _inputs("model", workloads.R50_LEVELS_INFER, 71, dev)
@@ -304,7 +304,8 @@ def test_backward_choice_follows_the_forward_reports_of_its_call_site(dev, api):
     with ext.call_site(42):
         for _ in range(72):
             fwd(far)
-        assert bwd(far)[0] == "msda_bwd_tiled"
+        k_far, g_far = bwd(far)
+        assert k_far == "msda_bwd_regions"                 # far fraction 0.93: the destination-side kernel
     with ext.call_site(41):
         for _ in range(72):
             fwd(near)
@@ -317,11 +318,14 @@ def test_backward_choice_follows_the_forward_reports_of_its_call_site(dev, api):
             torch.use_deterministic_algorithms(False)
         assert bwd(near)[0] == "msda_bwd_win"
     with ext.call_site(42):
-        assert bwd(near)[0] == "msda_bwd_tiled"            # site 41's reports are not site 42's
+        assert bwd(near)[0] == "msda_bwd_regions"          # site 41's reports are not site 42's (which has seen far samples only)
     with ext.call_site(41):
         for _ in range(12):
             fwd(far)
-        assert bwd(far)[0] == "msda_bwd_tiled"
+        assert bwd(far)[0] == "msda_bwd_regions"
+    ref_far = _bwd(MSDA, lib, far, go, "msda_bwd_tiled")
+    for a, b in zip(g_far, ref_far):
+        assert float((a - b).abs().max()) < 1e-4 * 168
     # the two kernels agree with each other far inside the oracle bounds
     ref = _bwd(MSDA, lib, near, go, "msda_bwd_tiled")
     for a, b in zip(g_near, ref):
@@ -451,7 +455,7 @@ def test_encoder_shaped_reference_fixture_forward(variant, dev, api):
     assert float(np.abs(out.cpu().numpy().reshape(g["out"].shape) - g["out"]).max()) < 1e-4
 
 
-@pytest.mark.parametrize("variant", ["auto", "msda_bwd_tiled", "msda_bwd_win", "msda_bwd_generic"])
+@pytest.mark.parametrize("variant", ["auto", "msda_bwd_tiled", "msda_bwd_win", "msda_bwd_regions", "msda_bwd_generic"])
 def test_encoder_shaped_reference_fixture_backward(variant, dev, api):
     """The backward kernels on the same fixture (autograd through the reference's function in float64)."""
     from golden_util import load_golden

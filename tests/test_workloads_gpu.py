@@ -59,7 +59,7 @@ def test_named_workload_forward_and_backward_every_query(name, flavour, dev, api
     go = torch.randn(N, Lq, 256, generator=torch.Generator().manual_seed(5)).to(dev)
     gv, gl, ga = MSDA.ms_deform_attn_backward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], go, 64)
     kernel = lib.last_kernel("backward")
-    assert kernel in (("msda_bwd_tiled", "msda_bwd_win") if encoder else ("msda_bwd_dec",)), kernel
+    assert kernel in (("msda_bwd_tiled", "msda_bwd_win", "msda_bwd_regions") if encoder else ("msda_bwd_dec",)), kernel
     ogv, ogl, oga = msda_oracle.backward(go, x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
     tgv, _, tga = msda_oracle.backward(go.double(), x["value"].double(), x["shapes"], x["lsi"], x["loc"].double(), x["attn"].double())
     e_gv = float(np.abs(gv.cpu().numpy().astype(np.float64) - tgv).max())

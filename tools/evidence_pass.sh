@@ -16,7 +16,7 @@ cat $O/trace_noextras.json >> $O/bench_kernel_trace_noextras.txt
 ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace_full -- python $R/bench.py --no-cpu-baseline > $O/trace_full.json 2> $O/trace_full.err )
 python tools/rocprof_summary.py trace $(find $O/trace_full -name "*_results.db" | head -1) > $O/bench_kernel_trace.txt 2>&1
 cat $O/trace_full.json >> $O/bench_kernel_trace.txt
-timeout 600 python tools/kbench.py --reps 18 --rotate 6 --variants-fwd 7,9,10,11,12 --variants-bwd 3,4,5 --flavours model,wide,uniform > $O/kbench_final.txt 2>&1
+timeout 600 python tools/kbench.py --reps 18 --rotate 6 --variants-fwd 7,9,10,11,12 --variants-bwd 3,4,5,6 --flavours model,wide,uniform > $O/kbench_final.txt 2>&1
 timeout 900 python tools/kbench.py --reps 12 --rotate 3 --workloads all --flavours model,wide > $O/kbench_workloads.txt 2>&1
 rm -rf $O/trace_noextras $O/trace_full $O/traffic_prof
 ls -la $O

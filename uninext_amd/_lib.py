@@ -57,6 +57,7 @@ def load():
         fh.argtypes, fh.restype = [p, p, p, p, p, i, i, i, i, i, i, i, p, i], i
         gh = getattr(lib, "msda_host_backward_" + suf)
         gh.argtypes, gh.restype = [p, p, p, p, p, p, i, i, i, i, i, i, i, p, p, p, i], i
+    lib.msda_host_last_num_threads.argtypes, lib.msda_host_last_num_threads.restype = [], i
     lib.msda_hip_forward_fused_f32.argtypes = [p, p, p, p, i, p, p, i, i, i, i, i, i, i, p, p]
     lib.msda_hip_forward_fused_f32.restype = i
     lib.msda_hip_forward_fused_hm_f32.argtypes = lib.msda_hip_forward_fused_f32.argtypes

@@ -28,7 +28,7 @@
 // All geometry comes from the int64 shape tensors on the device: the host never needs the level shapes
 // (no sync, graph-capturable).  The grid is persistent (2 workgroups per CU) and walks the items
 // head-minor, so a workgroup -- and, by the observed round-robin, an XCD -- stays on one head.
-#include "msda_common.hpp"
+#include "../msda_common.hpp"
 
 namespace msda {
 

@@ -24,7 +24,7 @@
 #include <cstring>
 #include <type_traits>
 
-#include "msda_common.hpp"
+#include "../msda_common.hpp"
 
 namespace msda {
 namespace {

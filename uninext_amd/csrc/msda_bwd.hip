@@ -393,11 +393,18 @@ int launch_backward<float>(int variant, const float* grad_out, const float* valu
   const bool tl = tiled_backward_ok(d);
   constexpr int kBwdWin = 4;            // backward variant 4: msda_bwd_win (value + gradient windows in LDS)
   constexpr int kBwdDec = 5;            // backward variant 5: msda_bwd_dec (decoder-style calls)
+  constexpr int kBwdRegions = 6;        // backward variant 6: msda_bwd_regions (destination-side sums, no global atomics)
   if (variant == kAuto) {
     // encoder-style calls: msda_bwd_win where the forward calls of the call site have reported near samples
-    // (win_backward_auto, msda_fwd_win.hip), msda_bwd_tiled otherwise; generic for everything else
+    // (backward_site_choice, msda_fwd_win.hip), msda_bwd_tiled otherwise; generic for everything else
     // decoder-style calls (fp32, D = 32, L = P = 4): msda_bwd_dec, LDS accumulators for the coarse levels
-    variant = (tl && d.S >= 1024) ? (win_backward_auto(d) ? kBwdWin : kTiled) : (dec_backward_ok(d) ? kBwdDec : kGeneric);
+    // ... and msda_bwd_regions where they have reported far ones (backward_site_choice, msda_fwd_win.hip)
+    if (tl && d.S >= 1024) {
+      const int site = backward_site_choice(d);
+      variant = site == 1 ? kBwdWin : site == 2 ? kBwdRegions : kTiled;
+    } else {
+      variant = dec_backward_ok(d) ? kBwdDec : kGeneric;
+    }
   }
   drop_call_context();
   if (variant == kBwdDec && dec_backward_ok(d)) {
@@ -405,6 +412,11 @@ int launch_backward<float>(int variant, const float* grad_out, const float* valu
     return launch_backward_dec(grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, stream);
   }
   if (variant == kBwdDec) variant = kGeneric;
+  if (variant == kBwdRegions && regions_backward_ok(d)) {
+    *kernel_name = "msda_bwd_regions";
+    return launch_backward_regions(grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, stream);
+  }
+  if (variant == kBwdRegions) variant = tl ? kTiled : kGeneric;
   if (variant == kBwdWin && win_backward_ok(d)) {
     *kernel_name = "msda_bwd_win";
     return launch_backward_win(grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, stream);

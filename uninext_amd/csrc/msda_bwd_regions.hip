@@ -310,7 +310,20 @@ Workspace g_ws[kMaxDevices];
 
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// bins <= N * M * S (a region holds at least one pixel); records <= 4 per sample
+inline size_t table_bytes(const Dims& d) { return align256(((size_t)d.N * d.M * d.S + 1) * 4); }
+inline size_t record_bytes(const Dims& d) { return align256((size_t)d.N * d.Lq * d.M * 16 * 4 * sizeof(Rec)); }
+
+// a workspace the CALLER lent to the next backward call of this thread (msda_hip_backward_ws_f32): consumed by that call
+thread_local void* t_call_ws = nullptr;
+thread_local size_t t_call_ws_bytes = 0;
+
 }  // namespace
+
+size_t regions_workspace_bytes(const Dims& d) {
+  return regions_backward_ok(d) ? 3 * table_bytes(d) + record_bytes(d) : 0;
+}
+void set_call_workspace(void* p, size_t bytes) { t_call_ws = p; t_call_ws_bytes = bytes; }
 
 bool regions_backward_ok(const Dims& d) {
   // encoder-shaped (the query-side pass is msda_bwd_tiled's), 4 levels; record slots and bins are 32-bit
@@ -334,34 +347,48 @@ int launch_backward_regions(const float* grad_out, const float* value, const int
   if (cap != hipStreamCaptureStatusNone)   // no allocation and no cross-stream hand-over inside a capture
     return launch_backward_tiled(grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, stream);
 
-  // bins <= N * M * S (a region holds at least one pixel); records <= 4 per sample
-  const size_t max_bins = (size_t)d.N * d.M * d.S + 1;
-  const size_t b_counts = align256(max_bins * 4), b_recs = align256((size_t)d.N * d.Lq * d.M * 16 * 4 * sizeof(Rec));
+  const size_t b_counts = table_bytes(d), b_recs = record_bytes(d);
+  void* const lent = t_call_ws;
+  const size_t lent_bytes = t_call_ws_bytes;
+  t_call_ws = nullptr;
+  t_call_ws_bytes = 0;
   Workspace& ws = g_ws[dev];
-  std::lock_guard<std::mutex> lock(ws.mu);
-  if (!ws.done && hipEventCreateWithFlags(&ws.done, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
-  // The tables sit at offsets that depend on the workspace's CAPACITY (a first version laid them out by the CALL's sizes: a
-  // smaller call after a larger one then found its `counts` inside the larger call's tables, not zero, and its records went
-  // wherever the garbage starts pointed -- found by the named-workload suite, which changes shapes from test to test).
-  if (ws.table_bytes < b_counts || ws.bytes < 3 * ws.table_bytes + b_recs) {
-    const size_t tb = std::max(ws.table_bytes, b_counts), rb = std::max(ws.bytes > 3 * ws.table_bytes ? ws.bytes - 3 * ws.table_bytes : 0, b_recs);
-    if (ws.buf) {
-      if (hipError_t e = hipDeviceSynchronize(); e != hipSuccess) return (int)e;   // (grows a few times per process at most)
-      (void)hipFree(ws.buf);
-      ws.buf = nullptr;
-      ws.bytes = ws.table_bytes = 0;
+  std::unique_lock<std::mutex> lock(ws.mu, std::defer_lock);
+  char* base;
+  size_t tb;
+  const bool own = !(lent && lent_bytes >= 3 * b_counts + b_recs && ((uintptr_t)lent & 255) == 0);
+  if (!own) {
+    // the caller's buffer (stream-ordered by the caller's allocator): tables laid out by this call's sizes, nothing survives
+    base = static_cast<char*>(lent);
+    tb = b_counts;
+  } else {
+    lock.lock();
+    if (!ws.done && hipEventCreateWithFlags(&ws.done, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+    // The tables sit at offsets that depend on the workspace's CAPACITY (a first version laid them out by the CALL's sizes: a
+    // smaller call after a larger one then found its `counts` inside the larger call's tables, not zero, and its records went
+    // wherever the garbage starts pointed -- found by the named-workload suite, which changes shapes from test to test).
+    if (ws.table_bytes < b_counts || ws.bytes < 3 * ws.table_bytes + b_recs) {
+      const size_t ntb = std::max(ws.table_bytes, b_counts), rb = std::max(ws.bytes > 3 * ws.table_bytes ? ws.bytes - 3 * ws.table_bytes : 0, b_recs);
+      if (ws.buf) {
+        if (hipError_t e = hipDeviceSynchronize(); e != hipSuccess) return (int)e;   // (grows a few times per process at most)
+        (void)hipFree(ws.buf);
+        ws.buf = nullptr;
+        ws.bytes = ws.table_bytes = 0;
+      }
+      if (hipError_t e = hipMalloc(reinterpret_cast<void**>(&ws.buf), 3 * ntb + rb); e != hipSuccess) return (int)e;
+      ws.bytes = 3 * ntb + rb;
+      ws.table_bytes = ntb;
+      ws.used = false;
+    } else if (ws.used && ws.last != stream) {
+      if (hipError_t e = hipStreamWaitEvent(stream, ws.done, 0); e != hipSuccess) return (int)e;
     }
-    if (hipError_t e = hipMalloc(reinterpret_cast<void**>(&ws.buf), 3 * tb + rb); e != hipSuccess) return (int)e;
-    ws.bytes = 3 * tb + rb;
-    ws.table_bytes = tb;
-    ws.used = false;
-  } else if (ws.used && ws.last != stream) {
-    if (hipError_t e = hipStreamWaitEvent(stream, ws.done, 0); e != hipSuccess) return (int)e;
+    base = ws.buf;
+    tb = ws.table_bytes;
   }
-  uint32_t* const counts = reinterpret_cast<uint32_t*>(ws.buf);
-  uint32_t* const starts = reinterpret_cast<uint32_t*>(ws.buf + ws.table_bytes);
-  uint32_t* const cursors = reinterpret_cast<uint32_t*>(ws.buf + 2 * ws.table_bytes);
-  Rec* const recs = reinterpret_cast<Rec*>(ws.buf + 3 * ws.table_bytes);
+  uint32_t* const counts = reinterpret_cast<uint32_t*>(base);
+  uint32_t* const starts = reinterpret_cast<uint32_t*>(base + tb);
+  uint32_t* const cursors = reinterpret_cast<uint32_t*>(base + 2 * tb);
+  Rec* const recs = reinterpret_cast<Rec*>(base + 3 * tb);
   // counts of this call's bins start at zero whatever an earlier (possibly aborted) call left: 1.4 MB, ~2 us
   if (hipError_t e = hipMemsetAsync(counts, 0, b_counts, stream); e != hipSuccess) return (int)e;
 
@@ -377,7 +404,7 @@ int launch_backward_regions(const float* grad_out, const float* value, const int
   hipLaunchKernelGGL(msda_bwd_regions_add, dim3((unsigned)(2 * cus)), dim3(kAddT), 0, stream, grad_out, shapes, lsi, d,
                      static_cast<const uint32_t*>(starts), static_cast<const Rec*>(recs), grad_value);
   const int rc = (int)hipGetLastError();
-  if (rc == 0) {
+  if (rc == 0 && own) {
     (void)hipEventRecord(ws.done, stream);
     ws.last = stream;
     ws.used = true;

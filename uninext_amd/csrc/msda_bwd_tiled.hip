@@ -105,11 +105,14 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-__global__ void __launch_bounds__(kBT, 3)
-msda_bwd_tiled(const float* __restrict__ grad_out, const float* __restrict__ value,
-               const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
-               const float* __restrict__ loc, const float* __restrict__ attn, Dims d,
-               float* __restrict__ grad_value, float* __restrict__ grad_loc, float* __restrict__ grad_attn) {
+// GV = false: grad_sampling_loc and grad_attn_weight only -- no accumulator windows, no far atomics, no flush; grad_value is
+// somebody else's (msda_bwd_regions.hip adds it on the destination side).
+template <bool GV>
+__device__ __forceinline__ void bwd_tiled_body(const float* __restrict__ grad_out, const float* __restrict__ value,
+                                               const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+                                               const float* __restrict__ loc, const float* __restrict__ attn, const Dims& d,
+                                               float* __restrict__ grad_value, float* __restrict__ grad_loc,
+                                               float* __restrict__ grad_attn) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   BwdMeta& mt = *reinterpret_cast<BwdMeta*>(smem + kBWinBytes + kBRecBytes);
   constexpr int P = kBP;
@@ -222,7 +225,8 @@ msda_bwd_tiled(const float* __restrict__ grad_out, const float* __restrict__ val
     }
     if (tid == 0) { mt.gmax_bits = 0u; mt.amax_bits = 0u; }
     // zero the accumulator windows (and the sink)
-    for (int o = tid * 16; o < nslots * kBSlotBytes; o += kBT * 16) *reinterpret_cast<f32x4*>(smem + o) = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (GV)
+      for (int o = tid * 16; o < nslots * kBSlotBytes; o += kBT * 16) *reinterpret_cast<f32x4*>(smem + o) = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
     int cum[kBMaxL + 1];
     cum[0] = 0;
@@ -265,7 +269,7 @@ msda_bwd_tiled(const float* __restrict__ grad_out, const float* __restrict__ val
       __syncthreads();
 
       // ---- fixed-point scale of this tile (LDS accumulation needs the whole tile in one round) ----------
-      const bool one_round = nq <= kBMaxTileQ;
+      const bool one_round = GV && nq <= kBMaxTileQ;
       if (one_round) {
         float gm = 0.f, am = 0.f;
         for (int e = tid; e < nround * 8; e += kBT) {   // (pair, lane of the pair)
@@ -435,7 +439,7 @@ msda_bwd_tiled(const float* __restrict__ grad_out, const float* __restrict__ val
             const uint32_t a1 = cur.ak[0] + lane_off, a2 = cur.ak[1] + lane_off, a3 = cur.ak[2] + lane_off, a4 = cur.ak[3] + lane_off;
 #endif
 #pragma unroll
-            for (int cp = 0; cp < 2; ++cp) {
+            for (int cp = 0; GV && cp < 2; ++cp) {
               const v2f g1 = tgs[cp] * wh.x, g2 = tgs[cp] * wl.x, g3 = tgs[cp] * wh.y, g4 = tgs[cp] * wl.y;
 #ifdef MSDA_BWD_NOCONF
               constexpr uint32_t kC0 = 256u, kC1 = 512u;
@@ -447,7 +451,7 @@ msda_bwd_tiled(const float* __restrict__ grad_out, const float* __restrict__ val
               lds_add(a3 + kC0 * cp, cvt_rn_i32(g3.x)); lds_add(a3 + kC0 * cp + kC1, cvt_rn_i32(g3.y));
               lds_add(a4 + kC0 * cp, cvt_rn_i32(g4.x)); lds_add(a4 + kC0 * cp + kC1, cvt_rn_i32(g4.y));
             }
-            far_any |= __ballot((flags & 16u) != 0u);
+            if constexpr (GV) far_any |= __ballot((flags & 16u) != 0u);
             const float ra = group8_sum(pa);
             const float rw = group8_sum(pwx) * (float)lvW[l];
             const float rh = group8_sum(phy) * (float)lvH[l];
@@ -508,7 +512,7 @@ msda_bwd_tiled(const float* __restrict__ grad_out, const float* __restrict__ val
     }
 
     // ---- flush: every touched window pixel leaves as one full-line atomic (32 lanes x 4 B) -------------
-    {
+    if constexpr (GV) {
       const int ch = tid & 31;
       const int b0 = mt.base[0], b1 = mt.base[1], b2 = mt.base[2], b3 = mt.base[3];
       for (int p = tid >> 5; p < nslots; p += kBT / 32) {
@@ -542,6 +546,22 @@ msda_bwd_tiled(const float* __restrict__ grad_out, const float* __restrict__ val
   }
 }
 
+__global__ void __launch_bounds__(kBT, 3)
+msda_bwd_tiled(const float* __restrict__ grad_out, const float* __restrict__ value,
+               const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+               const float* __restrict__ loc, const float* __restrict__ attn, Dims d,
+               float* __restrict__ grad_value, float* __restrict__ grad_loc, float* __restrict__ grad_attn) {
+  bwd_tiled_body<true>(grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn);
+}
+
+__global__ void __launch_bounds__(kBT, 3)
+msda_bwd_tiled_nogv(const float* __restrict__ grad_out, const float* __restrict__ value,
+                    const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+                    const float* __restrict__ loc, const float* __restrict__ attn, Dims d,
+                    float* __restrict__ grad_loc, float* __restrict__ grad_attn) {
+  bwd_tiled_body<false>(grad_out, value, shapes, lsi, loc, attn, d, nullptr, grad_loc, grad_attn);
+}
+
 // Host side ---------------------------------------------------------------------------------------
 bool tiled_backward_ok(const Dims& d) {
   return d.D == 32 && d.P == kBP && d.L <= kBMaxL && d.Lq == d.S &&
@@ -556,6 +576,17 @@ int launch_backward_tiled(const float* grad_out, const float* value, const int64
   // persistent grid: one 1024-thread workgroup per CU; a multiple of 8 so that item % M tracks blockIdx % 8
   hipLaunchKernelGGL(msda_bwd_tiled, dim3(256), dim3(kBT), kBLdsBytes, stream, grad_out, value, shapes, lsi, loc, attn,
                      d, grad_value, grad_loc, grad_attn);
+  return (int)hipGetLastError();
+}
+
+// grad_sampling_loc and grad_attn_weight only (first step of launch_backward_regions)
+int launch_backward_tiled_nogv(const float* grad_out, const float* value, const int64_t* shapes, const int64_t* lsi,
+                               const float* loc, const float* attn, const Dims& d, float* grad_loc, float* grad_attn,
+                               hipStream_t stream) {
+  static std::atomic<uint64_t> lds_opted_in{0};
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(msda_bwd_tiled_nogv), kBLdsBytes, lds_opted_in)) return rc;
+  hipLaunchKernelGGL(msda_bwd_tiled_nogv, dim3(256), dim3(kBT), kBLdsBytes, stream, grad_out, value, shapes, lsi, loc, attn,
+                     d, grad_loc, grad_attn);
   return (int)hipGetLastError();
 }
 

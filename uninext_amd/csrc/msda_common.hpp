@@ -114,6 +114,19 @@ int launch_backward_tiled(const float* grad_out, const float* value, const int64
                           const float* loc, const float* attn, const Dims& d, float* grad_value, float* grad_loc,
                           float* grad_attn, hipStream_t stream);
 
+int launch_backward_tiled_nogv(const float* grad_out, const float* value, const int64_t* shapes, const int64_t* lsi,
+                               const float* loc, const float* attn, const Dims& d, float* grad_loc, float* grad_attn,
+                               hipStream_t stream);   // grad_sampling_loc / grad_attn_weight only
+
+// msda_bwd_regions.hip: encoder backward with grad_value summed on the DESTINATION side (fp32, D = 32, L = P = 4, Lq == S):
+// no global atomics, time independent of where the samples fall
+bool regions_backward_ok(const Dims& d);
+size_t regions_workspace_bytes(const Dims& d);              // include/msda_hip.h: msda_hip_backward_workspace_bytes
+void set_call_workspace(void* p, size_t bytes);              // lent to the next backward call of this thread (nullptr: none)
+int launch_backward_regions(const float* grad_out, const float* value, const int64_t* shapes, const int64_t* lsi,
+                            const float* loc, const float* attn, const Dims& d, float* grad_value, float* grad_loc,
+                            float* grad_attn, hipStream_t stream);
+
 // msda_bwd_win.hip: encoder backward with value AND gradient windows in LDS (fp32, D = 32, L = P = 4, Lq == S).
 bool win_backward_ok(const Dims& d);
 // msda_bwd_dec.hip: decoder-style calls (fp32, D = 32, L = P = 4) with LDS accumulators for the coarse levels
@@ -127,7 +140,7 @@ int launch_backward_win(const float* grad_out, const float* value, const int64_t
 // msda_fwd_win.hip: encoder forward with LDS windows on all four levels (fp32, D = 32, L = P = 4, Lq == S).
 bool win_forward_ok(const Dims& d);
 bool win_forward_auto(const Dims& d, hipStream_t stream);   // auto dispatch: take the window kernel for this call? (consumes the call context)
-bool win_backward_auto(const Dims& d);                       // backward of a site whose forward calls reported near samples? (consumes the context)
+int backward_site_choice(const Dims& d);                     // backward of an encoder-shaped call: 1 = msda_bwd_win (the site's forward calls reported near samples), 2 = msda_bwd_regions (they reported far ones), 0 = no report to go by (consumes the context)
 void set_call_context(int slot, unsigned flags);            // include/msda_hip.h: msda_hip_set_call_context
 void drop_call_context();
 int launch_forward_win_fused(const float* value, int head_major, const int64_t* shapes, const int64_t* lsi,

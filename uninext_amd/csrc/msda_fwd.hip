@@ -340,155 +340,9 @@ int launch_forward_fused(int variant, const float* value, int head_major, const 
   return (int)hipGetLastError();
 }
 
-// ------------------------------------------------------------------------------------------------
-// msda_fwd_lgcl: the lane-group kernel with the COARSEST level(s) of head m resident in LDS.
-//
-// rocprof (profiles/) shows msda_fwd_lanegroup bound by the vector-L1 / TA rate: 40 M 64-byte
-// accesses per encoder call at one per clock per CU.  The trailing pyramid levels are tiny (level 3 of the R50
-// pyramid: 273 pixels = 35 KB per head) yet receive a quarter of all samples -- so a persistent workgroup copies
-// them into LDS once and serves those samples with ds_read_b128 for ANY sampling pattern (no tiles, no
-// heuristics), which takes 25 % of the load off the L1 path while the LDS pipe is otherwise idle.
-// fp32, D = 32, L*P = 16 with P = 4.  Workgroup (m, k) of image b walks the query chunks k, k + K, ...
+// (msda_fwd_lgcl -- the lane-group kernel with the coarsest level resident in LDS, variant 6 -- and msda_fwd_lgp -- msda_fwd_lg3
+// made persistent, variant 8 -- lost their A/B and live in experiments/msda_fwd_lg_variants.inc, built by `make experiments`.)
 constexpr int kClSlots = 280;                                   // resident pixels (35 KB) + one all-zero slot
-constexpr int kClLdsBytes = kLevelTableBytes + (kClSlots + 1) * 128 + (kBlock / 8) * (16 * 32 + 16);
-
-__global__ void __launch_bounds__(kBlock, 3)
-msda_fwd_lgcl(const float* __restrict__ value, const int64_t* __restrict__ shapes,
-              const int64_t* __restrict__ lsi, const float* __restrict__ loc,
-              const float* __restrict__ attn, Dims d, float* __restrict__ out) {
-  constexpr int G = 8, LPT = 16, P = 4, kPairs = kBlock / G;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  int* smp_H = reinterpret_cast<int*>(smem);
-  int* smp_W = smp_H + kMaxLP;
-  int* smp_start = smp_W + kMaxLP;
-  char* cl_base = smem + kLevelTableBytes;                       // resident pixels, 128 B each
-  char* rec_base = cl_base + (kClSlots + 1) * 128;
-  const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-
-  const int tid = threadIdx.x;
-  if (tid < LPT) {
-    const int l = tid / P;
-    smp_H[tid] = (int)shapes[2 * l];
-    smp_W[tid] = (int)shapes[2 * l + 1];
-    smp_start[tid] = (int)lsi[l];
-  }
-  __syncthreads();
-  // resident set = the last level, if it has at most kClSlots pixels (more levels would fit for small pyramids,
-  // but every extra specialisation of the gather loop costs registers for all of them)
-  int res_l = LPT / P, res_pix0 = d.S;
-  {
-    const int st = smp_start[LPT - 1];
-    if (d.S - st <= kClSlots) { res_l = LPT / P - 1; res_pix0 = st; }
-  }
-  res_l = __builtin_amdgcn_readfirstlane(res_l);
-  res_pix0 = __builtin_amdgcn_readfirstlane(res_pix0);
-  const int nres = d.S - res_pix0;
-
-  const int b = blockIdx.y;
-  const int m = blockIdx.x % d.M;
-  const int k0 = blockIdx.x / d.M, K = gridDim.x / d.M;
-  const uint32_t pix_bytes = (uint32_t)d.M * 128u;
-  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(value) + (int64_t)b * d.S * d.M * 32, 0, (int)((uint32_t)d.S * pix_bytes), 0x00020000);
-  const uint32_t head_off = (uint32_t)m * 128u;
-
-  // ---- copy the resident levels of (b, m) into LDS; slot `nres` stays zero for dead corners -----------
-  for (int i = tid >> 3; i <= nres; i += kBlock / 8) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (i < nres) v = buffer_load_f32x4(rsrc, (uint32_t)(res_pix0 + i) * pix_bytes + (uint32_t)(tid & 7) * 16u, head_off);
-    *reinterpret_cast<f32x4*>(cl_base + i * 128 + (tid & 7) * 16) = v;
-  }
-  __syncthreads();
-
-  const int g = tid / G, j = tid % G;
-  char* rec = rec_base + g * (LPT * 32 + 16);
-  const uint32_t lane_off = (uint32_t)j * 16u;
-  const uint32_t cl_addr0 = smem_base + kLevelTableBytes;        // LDS byte address of resident pixel 0
-  const uint32_t zero_slot = cl_addr0 + (uint32_t)nres * 128u;
-  const int nchunks = (d.Lq + kPairs - 1) / kPairs;
-
-  // The resident level count is only known on the device; branch ONCE into a loop specialised for it so that
-  // every gather step is either pure-LDS or pure-buffer at compile time (a per-step runtime branch makes the
-  // scheduler keep both paths' registers alive: 168 VGPRs + spills instead of ~70).
-  auto run = [&](auto res_tag) {
-    constexpr int RES_L = decltype(res_tag)::value;
-    for (int chunk = k0; chunk < nchunks; chunk += K) {
-      const int q = chunk * kPairs + g;
-      const bool live = q < d.Lq;
-      const int64_t pair = ((int64_t)b * d.Lq + (live ? q : 0)) * d.M + m;
-
-      auto prepare = [&](int s, float lx, float ly, float a) {
-        const int H = smp_H[s], W = smp_W[s];
-        const Sample<float> sm = make_sample<float>(lx, ly, H, W);
-        const float wa = sm.hh * a, wb = sm.lh * a;
-        float4 w;
-        w.x = (live && sm.ok1) ? wa * sm.hw : 0.f;
-        w.y = (live && sm.ok2) ? wa * sm.lw : 0.f;
-        w.z = (live && sm.ok3) ? wb * sm.hw : 0.f;
-        w.w = (live && sm.ok4) ? wb * sm.lw : 0.f;
-        const int pix1 = smp_start[s] + sm.h_low * W + sm.w_low;
-        u32x4 o;
-        if (s / P >= RES_L) {   // this sample's level lives in LDS
-          const uint32_t a1 = cl_addr0 + (uint32_t)(pix1 - res_pix0) * 128u;
-          o[0] = sm.ok1 ? a1 : zero_slot;
-          o[1] = sm.ok2 ? a1 + 128u : zero_slot;
-          o[2] = sm.ok3 ? a1 + (uint32_t)W * 128u : zero_slot;
-          o[3] = sm.ok4 ? a1 + (uint32_t)(W + 1) * 128u : zero_slot;
-        } else {
-          const uint32_t o1 = (uint32_t)pix1 * pix_bytes;
-          o[0] = sm.ok1 ? o1 : kOobOffset;
-          o[1] = sm.ok2 ? o1 + pix_bytes : kOobOffset;
-          o[2] = sm.ok3 ? o1 + (uint32_t)W * pix_bytes : kOobOffset;
-          o[3] = sm.ok4 ? o1 + (uint32_t)(W + 1) * pix_bytes : kOobOffset;
-        }
-        *reinterpret_cast<float4*>(rec + s * 32) = w;
-        *reinterpret_cast<u32x4*>(rec + s * 32 + 16) = o;
-      };
-      {
-        float4 lc = make_float4(0.f, 0.f, 0.f, 0.f);
-        float2 at = make_float2(0.f, 0.f);
-        if (live) {
-          lc = *reinterpret_cast<const float4*>(loc + pair * (2 * LPT) + 4 * j);
-          at = *reinterpret_cast<const float2*>(attn + pair * LPT + 2 * j);
-        }
-        prepare(2 * j, lc.x, lc.y, at.x);
-        prepare(2 * j + 1, lc.z, lc.w, at.y);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  #pragma unroll
-      for (int s = 0; s < LPT; ++s) {
-        const float4 w = *reinterpret_cast<const float4*>(rec + s * 32);
-        const u32x4 o = *reinterpret_cast<const u32x4*>(rec + s * 32 + 16);
-        f32x4 r1, r2, r3, r4;
-        if (s / P >= RES_L) {   // compile-time after unrolling
-          r1 = *reinterpret_cast<const f32x4 __attribute__((address_space(3)))*>((uintptr_t)(o[0] + lane_off));
-          r2 = *reinterpret_cast<const f32x4 __attribute__((address_space(3)))*>((uintptr_t)(o[1] + lane_off));
-          r3 = *reinterpret_cast<const f32x4 __attribute__((address_space(3)))*>((uintptr_t)(o[2] + lane_off));
-          r4 = *reinterpret_cast<const f32x4 __attribute__((address_space(3)))*>((uintptr_t)(o[3] + lane_off));
-        } else {
-          r1 = buffer_load_f32x4(rsrc, o[0] + lane_off, head_off);
-          r2 = buffer_load_f32x4(rsrc, o[1] + lane_off, head_off);
-          r3 = buffer_load_f32x4(rsrc, o[2] + lane_off, head_off);
-          r4 = buffer_load_f32x4(rsrc, o[3] + lane_off, head_off);
-        }
-  #pragma unroll
-        for (int c = 0; c < 4; ++c)
-          acc[c] = fmaf(w.w, r4[c], fmaf(w.z, r3[c], fmaf(w.y, r2[c], fmaf(w.x, r1[c], acc[c]))));
-      }
-      if (live) __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(out + pair * 32 + 4 * j));
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();   // the next chunk rewrites the records
-    }
-
-  };
-  if (res_l == LPT / P - 1) run(std::integral_constant<int, LPT / P - 1>{});
-  else run(std::integral_constant<int, LPT / P>{});
-}
-
 // ------------------------------------------------------------------------------------------------
 // msda_fwd_lg3: one-shot (non-persistent) 1024-thread workgroups of 128 queries x 1 head, last pyramid level
 // resident in LDS.  Lessons of msda_fwd_lgcl (profiles/): the gather needs ~32 waves per CU in flight;
@@ -699,225 +553,9 @@ static int launch_lg3(const float* value, const int64_t* shapes, const int64_t* 
   return launch_lg3_t<0>(value, shapes, lsi, loc, attn, nullptr, d, 0, out, stream);
 }
 
-// ------------------------------------------------------------------------------------------------
-// msda_fwd_lgp: msda_fwd_lg3 made persistent.  Timestamps inside msda_fwd_lg3 (profiles/r01_lg3_phases.txt) show a
-// 128-query workgroup living 14.4 us of which only 7.2 us issue gathers: 4.5 us go to the prologue (level table,
-// level copy, then the loc/attn loads queued behind it), 2.2 us to the second record pass + barrier, and the CU waits
-// another 1.8 us for the next 16-wave workgroup to be dispatched -- the texture path idles 42 % of the kernel.  Here
-// two workgroups per CU stay resident, copy the last level ONCE, and loop over query chunks with wave-level
-// synchronisation only; the next chunk's loc/attn are requested right after the last gather of the current one has
-// been issued, so the 16 waves drift apart and keep the L1 path fed.
-__global__ void __launch_bounds__(kL3Threads, 8)
-msda_fwd_lgp(const float* __restrict__ value, const int64_t* __restrict__ shapes,
-             const int64_t* __restrict__ lsi, const float* __restrict__ loc,
-             const float* __restrict__ attn, Dims d, int wg_per_head, float* __restrict__ out) {
-  constexpr int G = 8, LPT = 16, P = 4, kPairs = kL3Threads / G;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  int* smp_H = reinterpret_cast<int*>(smem);
-  int* smp_W = smp_H + kMaxLP;
-  int* smp_start = smp_W + kMaxLP;
-  char* cl_base = smem + kLevelTableBytes;
-  char* rec_base = cl_base + (kClSlots + 1) * 128;
-  const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-
-  const int tid = threadIdx.x;
-  if (tid < LPT) {
-    const int l = tid / P;
-    smp_H[tid] = (int)shapes[2 * l];
-    smp_W[tid] = (int)shapes[2 * l + 1];
-    smp_start[tid] = (int)lsi[l];
-  }
-  const int b = blockIdx.y;
-  const int m = blockIdx.x % d.M;
-  const int g = tid / G, j = tid % G;
-  const int nchunks = (d.Lq + kPairs - 1) / kPairs;
-  int chunk = blockIdx.x / d.M;
-  // loc / attn / out of image b as buffers of exactly Lq queries: the lanes of queries past the end read zeros
-  // (weight 0) and their stores are dropped -- no per-lane liveness to carry through the loop
-  const uint32_t qrow = (uint32_t)d.M * 128u;   // bytes of one query in loc and out (attn: half)
-  const __amdgpu_buffer_rsrc_t rloc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(loc) + (int64_t)b * d.Lq * d.M * 32, 0, (int)((uint32_t)d.Lq * qrow), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rattn = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(attn) + (int64_t)b * d.Lq * d.M * 16, 0, (int)((uint32_t)d.Lq * (qrow / 2)), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
-      out + (int64_t)b * d.Lq * d.M * 32, 0, (int)((uint32_t)d.Lq * qrow), 0x00020000);
-  // byte offset of this lane's first location inside a chunk of loc; attn: half of it; out: + 8 j
-  const uint32_t v_loc = (uint32_t)g * qrow + (uint32_t)m * 128u + (uint32_t)j * 8u;
-  const uint32_t chunk_bytes = (uint32_t)kPairs * qrow;
-  f32x2 lc0, lc1;
-  float at0, at1;
-  auto request = [&](int c) {   // c past the end: the offsets fall outside the buffers and everything reads 0
-    const uint32_t so = (uint32_t)c * chunk_bytes;
-    uint32_t vl = v_loc;
-    asm volatile("" : "+v"(vl));   // one address register; the other offsets are re-derived, not kept live
-    lc0 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rloc, vl, so, 0));
-    lc1 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rloc, vl + 64u, so, 0));
-    at0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rattn, vl >> 1, so / 2, 0));
-    at1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rattn, (vl >> 1) + 32u, so / 2, 0));
-  };
-  request(chunk);   // the first chunk's locations and weights are requested before anything else
-  __syncthreads();
-  const int res_pix0 = __builtin_amdgcn_readfirstlane(smp_start[LPT - 1]);   // first pixel of the last level
-  const int nres_all = d.S - res_pix0;
-  const bool fits = nres_all <= kClSlots;          // uniform; otherwise the last level also takes the L1 path
-  const int nres = fits ? nres_all : 0;
-  const uint32_t pix_bytes = qrow;
-  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(value) + (int64_t)b * d.S * d.M * 32, 0, (int)((uint32_t)d.S * pix_bytes), 0x00020000);
-  const uint32_t head_off = (uint32_t)m * 128u;
-  for (int i = tid >> 3; i <= nres && fits; i += kL3Threads / 8) {   // slot `nres` stays zero: dead corners read it
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (i < nres) v = buffer_load_f32x4(rsrc, (uint32_t)(res_pix0 + i) * pix_bytes + (uint32_t)(tid & 7) * 16u, head_off);
-    *reinterpret_cast<f32x4*>(cl_base + i * 128 + (tid & 7) * 16) = v;
-  }
-  __syncthreads();   // the only workgroup-wide wait: level copy complete
-
-  char* rec = rec_base + g * kL3RecPair;
-  const uint32_t lane_off = (uint32_t)j * 16u;
-  const uint32_t cl_addr0 = smem_base + kLevelTableBytes;
-  const uint32_t zero_slot = cl_addr0 + (uint32_t)nres * 128u;
-
-  auto prepare = [&](int s, f32x2 l, float a, bool resident) {
-    const int H = smp_H[s], W = smp_W[s];
-    const Sample<float> sm = make_sample<float>(l[0], l[1], H, W);
-    const float wa = sm.hh * a, wb = sm.lh * a;
-    float4 w;
-    w.x = sm.ok1 ? wa * sm.hw : 0.f;
-    w.y = sm.ok2 ? wa * sm.lw : 0.f;
-    w.z = sm.ok3 ? wb * sm.hw : 0.f;
-    w.w = sm.ok4 ? wb * sm.lw : 0.f;
-    const int pix1 = smp_start[s] + sm.h_low * W + sm.w_low;
-    u32x4 o;
-    if (resident) {
-      const uint32_t a1 = cl_addr0 + (uint32_t)(pix1 - res_pix0) * 128u;
-      o[0] = sm.ok1 ? a1 : zero_slot;
-      o[1] = sm.ok2 ? a1 + 128u : zero_slot;
-      o[2] = sm.ok3 ? a1 + (uint32_t)W * 128u : zero_slot;
-      o[3] = sm.ok4 ? a1 + (uint32_t)(W + 1) * 128u : zero_slot;
-    } else {
-      const uint32_t o1 = (uint32_t)pix1 * pix_bytes;
-      o[0] = sm.ok1 ? o1 : kOobOffset;
-      o[1] = sm.ok2 ? o1 + pix_bytes : kOobOffset;
-      o[2] = sm.ok3 ? o1 + (uint32_t)W * pix_bytes : kOobOffset;
-      o[3] = sm.ok4 ? o1 + (uint32_t)(W + 1) * pix_bytes : kOobOffset;
-    }
-    *reinterpret_cast<float4*>(rec + j * 32) = w;
-    *reinterpret_cast<u32x4*>(rec + j * 32 + 16) = o;
-  };
-  auto wave_sync = [] {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  };
-
-  // Two explicit register sets (A, B) alternate: the loads of sample s + 1 are issued before sample s is consumed.
-  // The scheduling barriers keep the compiler from hoisting every load of a pass to its top (it then spills: 64
-  // VGPRs is all that two 1024-thread workgroups per CU leave).
-#define MSDA_FETCH_G(X, slot)                                                             \
-  {                                                                                       \
-    X##w = *reinterpret_cast<const f32x4*>(rec + (slot) * 32);                            \
-    const u32x4 o_ = *reinterpret_cast<const u32x4*>(rec + (slot) * 32 + 16);             \
-    X##1 = buffer_load_f32x4(rsrc, o_[0] + lane_off, head_off);                           \
-    X##2 = buffer_load_f32x4(rsrc, o_[1] + lane_off, head_off);                           \
-    X##3 = buffer_load_f32x4(rsrc, o_[2] + lane_off, head_off);                           \
-    X##4 = buffer_load_f32x4(rsrc, o_[3] + lane_off, head_off);                           \
-    __builtin_amdgcn_sched_barrier(0);                                                    \
-  }
-#define MSDA_FETCH_L(X, slot)                                                             \
-  {                                                                                       \
-    typedef const f32x4 __attribute__((address_space(3)))* lp_;                           \
-    X##w = *reinterpret_cast<const f32x4*>(rec + (slot) * 32);                            \
-    const u32x4 o_ = *reinterpret_cast<const u32x4*>(rec + (slot) * 32 + 16);             \
-    X##1 = *reinterpret_cast<lp_>((uintptr_t)(o_[0] + lane_off));                         \
-    X##2 = *reinterpret_cast<lp_>((uintptr_t)(o_[1] + lane_off));                         \
-    X##3 = *reinterpret_cast<lp_>((uintptr_t)(o_[2] + lane_off));                         \
-    X##4 = *reinterpret_cast<lp_>((uintptr_t)(o_[3] + lane_off));                         \
-    __builtin_amdgcn_sched_barrier(0);                                                    \
-  }
-#define MSDA_CONSUME(X)                                                                   \
-  {                                                                                       \
-    _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_)                                      \
-      acc[c_] = fmaf(X##w[3], X##4[c_], fmaf(X##w[2], X##3[c_], fmaf(X##w[1], X##2[c_],   \
-                fmaf(X##w[0], X##1[c_], acc[c_]))));                                      \
-    asm volatile("" : "+v"(acc)); /* pins the FMAs here: IR-level sinking ignores sched_barrier */ \
-    __builtin_amdgcn_sched_barrier(0);                                                    \
-  }
-
-#pragma unroll 1
-  for (; chunk < nchunks; chunk += wg_per_head) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    f32x4 Aw, A1, A2, A3, A4, Bw, B1, B2, B3, B4;
-    // pass 0: samples 0..7 (levels 0 and 1) through the L1 path
-    prepare(j, lc0, at0, false);
-    wave_sync();
-    MSDA_FETCH_G(A, 0) MSDA_FETCH_G(B, 1) MSDA_CONSUME(A)
-    MSDA_FETCH_G(A, 2) MSDA_CONSUME(B) MSDA_FETCH_G(B, 3) MSDA_CONSUME(A)
-    MSDA_FETCH_G(A, 4) MSDA_CONSUME(B) MSDA_FETCH_G(B, 5) MSDA_CONSUME(A)
-    MSDA_FETCH_G(A, 6) MSDA_CONSUME(B) MSDA_FETCH_G(B, 7) MSDA_CONSUME(A) MSDA_CONSUME(B)
-    wave_sync();
-    // pass 1: samples 8..15 (levels 2 and 3); level 3 (slots 4..7) comes from the LDS copy
-    prepare(8 + j, lc1, at1, fits && j >= 4);
-    wave_sync();
-    MSDA_FETCH_G(A, 0) MSDA_FETCH_G(B, 1) MSDA_CONSUME(A)
-    MSDA_FETCH_G(A, 2) MSDA_CONSUME(B) MSDA_FETCH_G(B, 3) MSDA_CONSUME(A)
-    if (fits) {
-      request(chunk + wg_per_head);   // behind the last gather: in-order returns must not hold the gathers back
-      __builtin_amdgcn_sched_barrier(0);
-      MSDA_FETCH_L(A, 4) MSDA_CONSUME(B) MSDA_FETCH_L(B, 5) MSDA_CONSUME(A)
-      MSDA_FETCH_L(A, 6) MSDA_CONSUME(B) MSDA_FETCH_L(B, 7) MSDA_CONSUME(A) MSDA_CONSUME(B)
-    } else {
-      MSDA_FETCH_G(A, 4) MSDA_CONSUME(B) MSDA_FETCH_G(B, 5) MSDA_CONSUME(A)
-      MSDA_FETCH_G(A, 6) MSDA_CONSUME(B) MSDA_FETCH_G(B, 7) MSDA_CONSUME(A)
-      request(chunk + wg_per_head);
-      __builtin_amdgcn_sched_barrier(0);
-      MSDA_CONSUME(B)
-    }
-    {
-      uint32_t vl = v_loc;
-      asm volatile("" : "+v"(vl));
-      // (the chunk's offset goes into the per-lane offset, the scalar offset stays the immediate 0: behind a
-      // buffer_store_dwordx4 with an SGPR offset the compiler's hazard recogniser lets a VALU instruction overwrite the data
-      // registers in the very next slot, and on gfx950 that store then writes the new value in some lanes --
-      // msda_fwd_win3.hip, found the hard way; nothing overwrote `acc` that early here, but nothing guaranteed it either)
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc), rout,
-                                             vl + (lane_off >> 1) + (uint32_t)chunk * chunk_bytes, 0, 2 /* nt */);
-    }
-    wave_sync();   // the next chunk rewrites the records
-  }
-#undef MSDA_FETCH_G
-#undef MSDA_FETCH_L
-#undef MSDA_CONSUME
-}
-
-static int launch_lgp(const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc,
-                      const float* attn, const Dims& d, float* out, hipStream_t stream) {
-  static std::atomic<uint64_t> lds_opted_in{0};
-  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(msda_fwd_lgp), kL3LdsBytes, lds_opted_in)) return rc;
-  constexpr int kPairs = kL3Threads / 8;
-  const int nchunks = (d.Lq + kPairs - 1) / kPairs;
-  int K = (2 * 256) / (d.M * d.N);   // two resident workgroups per CU
-  if (K < 1) K = 1;
-  if (K > nchunks) K = nchunks;
-  dim3 grid((unsigned)(d.M * K), (unsigned)d.N);
-  hipLaunchKernelGGL(msda_fwd_lgp, grid, dim3(kL3Threads), kL3LdsBytes, stream, value, shapes, lsi, loc, attn, d, K,
-                     out);
-  return (int)hipGetLastError();
-}
-
-static inline bool lgcl_ok(const Dims& d) {
-  return d.D == 32 && d.P == 4 && d.L == 4 && (int64_t)d.S * d.M * 128 < (int64_t)kOobOffset && d.N <= 65535 &&
-         d.Lq >= 4096;   // the resident copy is amortised over >= 2 query chunks per workgroup
-}
-
-static int launch_lgcl(const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc,
-                       const float* attn, const Dims& d, float* out, hipStream_t stream) {
-  const int nchunks = (d.Lq + 31) / 32;
-  int K = 768 / (d.M * d.N);   // ~3 resident workgroups per CU
-  K = K < 1 ? 1 : (K > nchunks ? nchunks : K);
-  hipLaunchKernelGGL(msda_fwd_lgcl, dim3((unsigned)(d.M * K), (unsigned)d.N), dim3(kBlock), kClLdsBytes, stream, value,
-                     shapes, lsi, loc, attn, d, out);
-  return (int)hipGetLastError();
-}
+#ifdef MSDA_EXPERIMENTS
+#include "experiments/msda_fwd_lg_variants.inc"
+#endif
 
 // ------------------------------------------------------------------------------------------------
 static inline bool lanegroup_ok(const Dims& d, int* G_out) {
@@ -951,13 +589,18 @@ int launch_forward<float>(int variant, const float* value, const int64_t* shapes
                           const char** kernel_name) {
   int G = 0;
   const bool lg = lanegroup_ok(d, &G);
+#ifdef MSDA_EXPERIMENTS
   const bool tl = tiled_forward_ok(d);
+#else
+  const bool tl = false;   // variants 3..5 are not in this build: they resolve to the lane-group kernel
+#endif
   // kbench A/B (profiles/): msda_fwd_lg3 beats msda_fwd_lanegroup by 14-20 % from ~1000 queries on; the tiled and
   // lgcl kernels lose and stay opt-in
   // ... and the LDS-window kernel beats msda_fwd_lg3 on the encoder shape while the samples stay near their queries:
   // win_forward_auto follows the locality the window kernel itself reported for the latest launches
   if (variant == kAuto) variant = win_forward_auto(d, stream) ? kWin : (lg3_ok(d) ? kLaneGroupL3 : (lg ? kLaneGroup : kGeneric));
   else drop_call_context();
+#ifdef MSDA_EXPERIMENTS   // the generations of the window kernel that lost their A/B (experiments/, `make experiments`)
   if (variant == kWin4 && !win4_forward_ok(d)) variant = lg3_ok(d) ? kLaneGroupL3 : kLaneGroup;
   if (variant == kWin4) {
     *kernel_name = "msda_fwd_win4";
@@ -973,6 +616,7 @@ int launch_forward<float>(int variant, const float* value, const int64_t* shapes
     *kernel_name = "msda_fwd_win2";
     return launch_forward_win2(value, shapes, lsi, loc, attn, d, out, stream);
   }
+#endif
   if (variant == kWin && !win_forward_ok(d)) variant = lg3_ok(d) ? kLaneGroupL3 : kLaneGroup;
   if (variant == kWin) {
     *kernel_name = "msda_fwd_win";
@@ -983,6 +627,7 @@ int launch_forward<float>(int variant, const float* value, const int64_t* shapes
     *kernel_name = "msda_fwd_lg3";
     return launch_lg3(value, shapes, lsi, loc, attn, d, out, stream);
   }
+#ifdef MSDA_EXPERIMENTS
   if (variant == kLaneGroupP && !lg3_ok(d)) variant = kLaneGroup;
   if (variant == kLaneGroupP) {
     *kernel_name = "msda_fwd_lgp";
@@ -993,12 +638,15 @@ int launch_forward<float>(int variant, const float* value, const int64_t* shapes
     *kernel_name = "msda_fwd_lgcl";
     return launch_lgcl(value, shapes, lsi, loc, attn, d, out, stream);
   }
+#endif
   if (variant >= kTiled && !tl) variant = lg ? kLaneGroup : kGeneric;
   if (variant == kLaneGroup && !lg) variant = kGeneric;
+#ifdef MSDA_EXPERIMENTS
   if (variant >= kTiled) {
     *kernel_name = "msda_fwd_tiled";
     return launch_forward_tiled(variant - kTiled, value, shapes, lsi, loc, attn, d, out, stream);
   }
+#endif
   if (variant == kLaneGroup) {
     const int LP = d.L * d.P;
     *kernel_name = "msda_fwd_lanegroup";

@@ -823,21 +823,27 @@ int forward_locality(double* far_fraction) {
 // the call sequence like the forward's.  Measured (profiles/r03_backward_window.txt): far 0.02 -> 336 us against 360,
 // far 0.41 -> 1128 against 924; the lines cross near 0.06.
 constexpr double kFarFractionMaxBwd = 0.05;
-bool win_backward_auto(const Dims& d) {
+// ... and msda_bwd_regions (destination-side sums, no global atomics: 0.7-0.9 ms whatever the locations) from the far fraction
+// on at which msda_bwd_tiled's far-corner atomics cost more than that (tiled: 0.02 -> 0.37 ms, 0.41 -> 0.91 ms, 0.93 -> 2.07 ms;
+// regions 0.78 / 0.71 / 0.89 ms on the same inputs: the lines cross near 0.25; profiles/r03_backward_regions.txt)
+constexpr double kFarFractionMinRegions = 0.30;
+int backward_site_choice(const Dims& d) {
   static const int mode_env = [] { const char* e = std::getenv("MSDA_HIP_FWD_ADAPTIVE"); return e ? std::atoi(e) : 1; }();
   const CallContext ctx = t_ctx;
   t_ctx = CallContext();
   t_pending = Pending();
   if (mode_env == 0 || !ctx.set || ctx.slot < 0 || ctx.slot >= kSites || !(ctx.flags & 1u) || (ctx.flags & 2u) ||
       !win_backward_ok(d))
-    return false;
+    return 0;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices ||
       g_loc_ready[dev].load(std::memory_order_acquire) != 1)
-    return false;                                 // no forward call has dispatched automatically on this device yet
+    return 0;                                     // no forward call has dispatched automatically on this device yet
   Slot& sl = g_loc[dev]->slots[ctx.slot];
   std::lock_guard<std::mutex> lock(sl.mu);
-  return sl.mode == 1 && sl.far <= kFarFractionMaxBwd;
+  if (sl.mode == 1 && sl.far <= kFarFractionMaxBwd) return 1;
+  if (sl.mode == 2 && sl.far >= kFarFractionMinRegions && regions_backward_ok(d)) return 2;
+  return 0;
 }
 
 bool win_forward_auto(const Dims& d, hipStream_t stream) {

@@ -40,23 +40,32 @@ int check(const HostDims& d, bool ptrs_ok) {
 int check_geometry(const HostDims& d, const int64_t* shapes, const int64_t* lsi) {
   for (int l = 0; l < d.L; ++l) {
     const int64_t H = shapes[2 * l], W = shapes[2 * l + 1], st = lsi[l];
-    if (H <= 0 || W <= 0 || H > (int64_t)d.S || W > (int64_t)d.S || st < 0 || st + H * W > (int64_t)d.S)
+    // H, W <= S first: H * W <= S * S then fits int64, and the start is compared WITHOUT an addition (a start near INT64_MAX
+    // would wrap negative and pass)
+    if (H <= 0 || W <= 0 || H > (int64_t)d.S || W > (int64_t)d.S || st < 0 || H * W > (int64_t)d.S ||
+        st > (int64_t)d.S - H * W)
       return dynmask_set_error(MSDA_ERR_BAD_DIMS, "spatial_shapes / level_start_index do not fit spatial_size");
   }
   return 0;
 }
 
-int thread_count(int requested, int64_t items) {
+// items = independent units the call can be split into; work = the call's size in cheap units (output rows / samples
+// rows): the backward's units are whole (image, head) slices of Lq rows each, so its thread count must not be derived
+// from the NUMBER of slices (16 slices / 256 = 0 -> one thread, an N * M-fold slow-down of the default CPU backward).
+int thread_count(int requested, int64_t items, int64_t work) {
   int n = requested > 0 ? requested : (int)std::thread::hardware_concurrency();
-  // threads are created per call: not more than one per ~256 work units (a 600-row decoder call gets 2-3, not 256)
-  if (requested <= 0) n = (int)std::min<int64_t>(n, std::max<int64_t>(1, items / 256));
+  // threads are created per call: not more than one per ~256 rows of work (a 600-row decoder call gets 2-3, not 256)
+  if (requested <= 0) n = (int)std::min<int64_t>(n, std::max<int64_t>(1, work / 256));
   if (n < 1) n = 1;
   if ((int64_t)n > items) n = (int)std::max<int64_t>(items, 1);
   return n;
 }
 
+thread_local int t_last_threads = 0;   // msda_host_last_num_threads(): what the last call of this thread ran on
+
 template <typename F>
 void parallel_for(int64_t items, int threads, F&& body) {   // body(begin, end)
+  t_last_threads = threads <= 1 ? 1 : threads;
   if (threads <= 1) { body((int64_t)0, items); return; }
   std::vector<std::thread> pool;
   pool.reserve(threads);
@@ -101,7 +110,7 @@ int forward_host(const T* value, const int64_t* shapes, const int64_t* lsi, cons
   const int64_t rows = (int64_t)d.N * d.Lq;
   const int64_t pix_stride = (int64_t)d.M * d.D;
   const int LP = d.L * d.P;
-  parallel_for(rows, thread_count(num_threads, rows), [&](int64_t lo, int64_t hi) {
+  parallel_for(rows, thread_count(num_threads, rows, rows), [&](int64_t lo, int64_t hi) {
     std::vector<T> acc((size_t)d.D);
     for (int64_t row = lo; row < hi; ++row) {
       const int64_t b = row / d.Lq;
@@ -144,7 +153,7 @@ int backward_host(const T* grad_out, const T* value, const int64_t* shapes, cons
   const int64_t slices = (int64_t)d.N * d.M;     // a thread owns grad_value[b, :, m, :]
   const int64_t pix_stride = (int64_t)d.M * d.D;
   const int LP = d.L * d.P;
-  parallel_for(slices, thread_count(num_threads, slices), [&](int64_t lo, int64_t hi) {
+  parallel_for(slices, thread_count(num_threads, slices, slices * (int64_t)d.Lq), [&](int64_t lo, int64_t hi) {
     for (int64_t sl = lo; sl < hi; ++sl) {
       const int64_t b = sl / d.M;
       const int m = (int)(sl % d.M);
@@ -228,5 +237,8 @@ int msda_host_backward_f64(const double* grad_output, const double* value, const
   return backward_host<double>(grad_output, value, spatial_shapes, level_start_index, sampling_loc, attn_weight, d,
                                grad_value, grad_sampling_loc, grad_attn_weight, num_threads);
 }
+
+
+int msda_host_last_num_threads(void) { return t_last_threads; }
 
 }  // extern "C"
