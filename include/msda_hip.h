@@ -44,6 +44,7 @@
 #ifndef MSDA_HIP_H_
 #define MSDA_HIP_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -103,6 +104,36 @@ int msda_hip_backward_f32(const float* grad_output, const float* value,
                           int spatial_size, int num_heads, int channels, int num_levels,
                           int num_query, int num_point, float* grad_value,
                           float* grad_sampling_loc, float* grad_attn_weight, void* stream);
+
+/*
+ * Workspace of the backward.  One kernel family needs scratch memory: msda_bwd_regions (encoder-shaped fp32 calls whose call
+ * site reported far samples, or backward variant 6) files one 32-byte record per (sample, destination region) before it sums
+ * them -- three bin tables plus up to four records per sample, ~0.7 GB at the R50 training shapes.
+ *
+ *   msda_hip_backward_workspace_bytes(dims...)   the bytes a call with these sizes may need: 0 when no kernel it can take
+ *                                                uses a workspace (decoder-shaped calls, fp64, other channel counts).
+ *   msda_hip_backward_ws_f32(..., workspace, workspace_bytes, stream)
+ *                                                msda_hip_backward_f32 with a workspace LENT by the caller for this call:
+ *                                                device memory, 256-byte aligned, at least ..._workspace_bytes; contents
+ *                                                undefined before and after; it must stay valid until the work enqueued on
+ *                                                `stream` by this call has completed (a stream-ordered allocator such as
+ *                                                PyTorch's caching allocator gives exactly that).  NULL / too small / not
+ *                                                aligned: the library's own workspace, as for msda_hip_backward_f32.
+ *
+ * Without a lent workspace the library keeps ONE buffer per device, allocated (hipMalloc) at the first call that needs
+ * it, grown with a device synchronisation when a larger call arrives, and handed from stream to stream behind an event;
+ * inside a stream capture such a call takes msda_bwd_tiled instead (no allocation in a capture).  With a lent workspace
+ * none of that happens: no allocation, no synchronisation, capturable.
+ */
+size_t msda_hip_backward_workspace_bytes(int batch, int spatial_size, int num_heads, int channels, int num_levels,
+                                         int num_query, int num_point);
+int msda_hip_backward_ws_f32(const float* grad_output, const float* value,
+                             const int64_t* spatial_shapes, const int64_t* level_start_index,
+                             const float* sampling_loc, const float* attn_weight, int batch,
+                             int spatial_size, int num_heads, int channels, int num_levels,
+                             int num_query, int num_point, float* grad_value,
+                             float* grad_sampling_loc, float* grad_attn_weight, void* workspace,
+                             size_t workspace_bytes, void* stream);
 
 int msda_hip_backward_f64(const double* grad_output, const double* value,
                           const int64_t* spatial_shapes, const int64_t* level_start_index,
@@ -180,7 +211,10 @@ int msda_host_last_num_threads(void);
  * Kernel selection (tuning / A-B measurement only; results are identical up to fp32
  * summation order).  which: 0 = forward, 1 = backward.  variant: 0 = automatic (default),
  * 1 = generic one-thread-per-output kernel, 2 = lane-group gather kernel, higher numbers as
- * listed by msda_hip_variant_name().  Returns 0 or MSDA_ERR_BAD_VARIANT.
+ * listed by msda_hip_variant_name().  Returns 0 or MSDA_ERR_BAD_VARIANT.  Numbers are stable across builds; the kernels
+ * that lost their A/B (forward 3-6, 8, 10-12) are compiled only into the experiments build (`make -C uninext_amd/csrc
+ * experiments` -> libmsda_hip_exp.so): in the default library their names read "exp:<kernel>" and selecting one returns
+ * MSDA_ERR_BAD_VARIANT.  Backward variants: 1..6; anything else is MSDA_ERR_BAD_VARIANT.
  */
 int msda_hip_set_variant(int which, int variant);
 int msda_hip_get_variant(int which);

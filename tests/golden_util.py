@@ -67,3 +67,17 @@ def grad_loc_err(gl, ref, shapes):
         if d[:, :, :, l].size:
             worst = max(worst, float(d[:, :, :, l].max()) / (1e-4 * max(h, w)))
     return worst
+
+
+def carried(which, *names):
+    """Of the kernel variants `names`, those the loaded library carries.  The default build leaves the kernels that lost
+    their A/B out (uninext_amd/csrc/experiments/, names 'exp:...'); with MSDA_HIP_LIB=.../libmsda_hip_exp.so
+    (`make -C uninext_amd/csrc experiments`) the same tests cover them again."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from uninext_amd import _lib
+    have = set(_lib.variants(which))
+    return [n for n in names if n == "auto" or n in have]

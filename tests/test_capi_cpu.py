@@ -55,10 +55,21 @@ def test_dynmask_header_symbols_are_exported(lib):
 def test_abi_version_and_variant_table(lib):
     from uninext_amd import _lib
     assert lib.msda_hip_abi_version() == _lib.ABI_VERSION == 1
-    assert _lib.variants("forward") == ["auto", "msda_fwd_generic", "msda_fwd_lanegroup", "msda_fwd_tiled",
-                                        "msda_fwd_tiled_l0", "msda_fwd_tiled_l0big", "msda_fwd_lgcl", "msda_fwd_lg3", "msda_fwd_lgp",
-                                        "msda_fwd_win", "msda_fwd_win2", "msda_fwd_win3", "msda_fwd_win4"]
-    assert _lib.variants("backward")[:4] == ["auto", "msda_bwd_generic", "msda_bwd_lanegroup", "msda_bwd_tiled"]
+    # numbers are stable; the default build names the kernels it does not carry "exp:..." and refuses to select them
+    full = ["auto", "msda_fwd_generic", "msda_fwd_lanegroup", "msda_fwd_tiled", "msda_fwd_tiled_l0", "msda_fwd_tiled_l0big",
+            "msda_fwd_lgcl", "msda_fwd_lg3", "msda_fwd_lgp", "msda_fwd_win", "msda_fwd_win2", "msda_fwd_win3", "msda_fwd_win4"]
+    got = _lib.variants("forward")
+    assert [n.replace("exp:", "") for n in got] == full
+    experiments = [k for k, n in enumerate(got) if n.startswith("exp:")]
+    if "MSDA_HIP_LIB" not in os.environ:
+        assert experiments == [3, 4, 5, 6, 8, 10, 11, 12]
+    for k in experiments:
+        assert lib.msda_hip_set_variant(0, k) != 0 and "experiment" in _lib.last_error()
+    assert _lib.variants("backward") == ["auto", "msda_bwd_generic", "msda_bwd_lanegroup", "msda_bwd_tiled", "msda_bwd_win",
+                                         "msda_bwd_dec", "msda_bwd_regions"]
+    for k in (7, 12, 99, -1):       # (slots 7..12 used to alias msda_bwd_tiled silently)
+        assert lib.msda_hip_set_variant(1, k) != 0 and lib.msda_hip_variant_name(1, k) is None
+    assert lib.msda_hip_get_variant(1) == 0
     with pytest.raises(ValueError):
         _lib.set_variant("forward", 99)
     _lib.set_variant("forward", "msda_fwd_generic")

@@ -19,8 +19,8 @@ CSRC = os.path.join(ROOT, "uninext_amd", "csrc")
 LIMITS = {
     "msda_fwd.hip": {"msda::msda_fwd_lg3<0>": (64, 0), "msda::msda_fwd_lanegroup<8, 16>": (64, 0)},
     "msda_fwd_win.hip": {"msda::msda_fwd_win<0, false>": (128, 8), "msda::msda_fwd_win<0, true>": (128, 8)},
-    "msda_fwd_win2.hip": {"msda::msda_fwd_win2": (80, 0)},
-    "msda_fwd_win3.hip": {"msda::msda_fwd_win3": (168, 0)},
+    "experiments/msda_fwd_win2.hip": {"msda::msda_fwd_win2": (80, 0)},
+    "experiments/msda_fwd_win3.hip": {"msda::msda_fwd_win3": (168, 0)},
     "msda_bwd_win.hip": {"msda::msda_bwd_win": (168, 0)},
     "msda_bwd_tiled.hip": {"msda::msda_bwd_tiled": (168, 0)},
     "msda_bwd.hip": {"msda::msda_bwd_generic<float, 1>": (96, 0)},

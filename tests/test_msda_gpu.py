@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import golden_names, grad_loc_err, load_golden, max_abs, scaled_err
+from golden_util import carried, golden_names, grad_loc_err, load_golden, max_abs, scaled_err
 
 pytestmark = pytest.mark.gpu
 
@@ -189,7 +189,7 @@ TILED_PYRAMIDS = [
 ]
 
 
-TILED_VARIANTS = ["msda_fwd_tiled", "msda_fwd_tiled_l0", "msda_fwd_tiled_l0big"]
+TILED_VARIANTS = carried("forward", "msda_fwd_tiled", "msda_fwd_tiled_l0", "msda_fwd_tiled_l0big")   # experiments build only
 
 
 @pytest.mark.parametrize("variant", TILED_VARIANTS)
@@ -240,7 +240,7 @@ def test_tiled_forward_head_point_counts(M, L, P, variant, dev, api):
     ("encoder", "model", ((64, 80), (32, 40), (16, 20), (17, 17))),        # last level 289 px: too big, nothing resident
     ("decoder", "model", ((64, 80), (32, 40), (16, 20), (8, 10))),         # Lq = 5000 arbitrary queries
 ])
-@pytest.mark.parametrize("variant", ["msda_fwd_lgcl", "msda_fwd_lg3", "msda_fwd_lgp"])
+@pytest.mark.parametrize("variant", carried("forward", "msda_fwd_lgcl", "msda_fwd_lg3", "msda_fwd_lgp"))
 def test_lgcl_forward_vs_oracle(kind, flavour, levels, variant, dev, api):
     """Lane-group kernel with the last pyramid level resident in LDS (any query set, any sampling pattern)."""
     from oracle import msda_oracle
@@ -276,7 +276,7 @@ def test_full_size_encoder_forward(flavour, dev, api):
     assert out.shape == (2, 22223, 256)
     auto_kernel = lib.last_kernel("forward")
     assert auto_kernel in ("msda_fwd_lg3", "msda_fwd_win")
-    for other in ("msda_fwd_lanegroup", "msda_fwd_tiled_l0", "msda_fwd_lgcl", "msda_fwd_lg3", "msda_fwd_lgp", "msda_fwd_win"):   # every fast kernel
+    for other in carried("forward", "msda_fwd_lanegroup", "msda_fwd_tiled_l0", "msda_fwd_lgcl", "msda_fwd_lg3", "msda_fwd_lgp", "msda_fwd_win"):   # every fast kernel
         lib.set_variant("forward", other)
         try:
             out_o = MSDA.ms_deform_attn_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], 64)

@@ -21,6 +21,8 @@ import numpy as np
 import pytest
 import torch
 
+from golden_util import carried
+
 pytestmark = pytest.mark.gpu
 
 ODD_PYRAMIDS = [
@@ -80,7 +82,7 @@ def test_full_size_forward_every_query(flavour, dev, api):
     MSDA, lib = api
     x = _inputs(flavour, workloads.R50_LEVELS_INFER, 13, dev)
     ref = msda_oracle.forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
-    for variant in ("auto", "msda_fwd_lanegroup", "msda_fwd_win", "msda_fwd_win2", "msda_fwd_win3", "msda_fwd_win4"):
+    for variant in carried("forward", "auto", "msda_fwd_lanegroup", "msda_fwd_win", "msda_fwd_win2", "msda_fwd_win3", "msda_fwd_win4"):
         out = _fwd(MSDA, lib, x, variant)
         want = lib.last_kernel("forward")
         assert want in (("msda_fwd_lg3", "msda_fwd_win") if variant == "auto" else (variant,))
@@ -89,7 +91,7 @@ def test_full_size_forward_every_query(flavour, dev, api):
         assert err < 1e-4, (variant, err)
 
 
-@pytest.mark.parametrize("kernel", ["msda_fwd_win", "msda_fwd_win2", "msda_fwd_win3", "msda_fwd_win4"])
+@pytest.mark.parametrize("kernel", carried("forward", "msda_fwd_win", "msda_fwd_win2", "msda_fwd_win3", "msda_fwd_win4"))
 @pytest.mark.parametrize("flavour", ["model", "uniform", "wide"])
 @pytest.mark.parametrize("levels", ODD_PYRAMIDS)
 def test_window_forward_on_odd_pyramids(levels, flavour, kernel, dev, api):
@@ -225,7 +227,7 @@ def test_window_forward_falls_back_outside_its_geometry(dev, api):
 
 
 @pytest.mark.parametrize("kernel", ENCODER_BWD)
-@pytest.mark.parametrize("flavour", ["model", "uniform"])
+@pytest.mark.parametrize("flavour", ["model", "wide", "uniform"])
 def test_full_size_backward_every_query(flavour, kernel, dev, api):
     from oracle import msda_oracle
     from uninext_amd import workloads
@@ -385,6 +387,30 @@ def test_tiled_backward_fixed_point_bound_under_high_dynamic_range(kernel, dev, 
     assert float(err_f.max()) < 1e-5 * gmax
 
 
+@pytest.mark.parametrize("kernel,kind", [("msda_bwd_tiled", "encoder"), ("msda_bwd_win", "encoder"), ("msda_bwd_dec", "decoder")])
+def test_fixed_point_backward_with_huge_upstream_gradients(kernel, kind, dev, api):
+    """the scale exponent of the int32 LDS accumulators is clamped to [-90, 90]; a bound >= 2^121 (grad_output
+    around 1e36) then scaled to 2^38 and wrapped silently.  Such tiles take the float-atomic path now: the result stays within
+    float32 accumulation error of the float64 oracle, relative to the largest gradient."""
+    from oracle import msda_oracle
+    from uninext_amd import workloads
+    MSDA, lib = api
+    levels = ((48, 64), (24, 32), (12, 16), (6, 8))
+    x = workloads.make_inputs(kind, "model", batch=2, levels=levels, num_query=None if kind == "encoder" else 300, seed=43, device=dev)
+    Lq = x["loc"].shape[1]
+    g = torch.Generator().manual_seed(44)
+    go = torch.randn(2, Lq, 256, generator=g).to(dev)
+    for scale in (1e35, 3e30):   # bounds ~1e38 (past 2^120: float atomics) and ~3e33 (fixed point, exponent -82)
+        gv, gl, ga = _bwd(MSDA, lib, x, go * scale, kernel)
+        assert lib.last_kernel("backward") == kernel
+        tgv, _, _ = msda_oracle.backward((go * scale).double(), x["value"].double(), x["shapes"], x["lsi"], x["loc"].double(), x["attn"].double())
+        gvn = gv.cpu().numpy().astype(np.float64)
+        assert np.isfinite(gvn).all()
+        rel = float(np.abs(gvn - tgv).max() / np.abs(tgv).max())
+        print("%s scale %.0e: max |err| / max |grad_value| = %.2e" % (kernel, scale, rel))
+        assert rel < 1e-5, rel
+
+
 @pytest.mark.parametrize("kernel", ["msda_bwd_dec", "msda_bwd_generic"])
 def test_full_size_decoder_backward_every_query(kernel, dev, api):
     from oracle import msda_oracle
@@ -441,7 +467,7 @@ print("KERNELS", captured_kernel, eager_kernel, _lib.forward_locality()[0])
     assert line[1] == "msda_fwd_lg3" and line[2] == "msda_fwd_win" and int(line[3]) == 1, line   # captured: gather; eager: window, 1 report
 
 
-@pytest.mark.parametrize("variant", ["auto", "msda_fwd_win", "msda_fwd_win2", "msda_fwd_win3", "msda_fwd_win4", "msda_fwd_lg3", "msda_fwd_lanegroup"])
+@pytest.mark.parametrize("variant", carried("forward", "auto", "msda_fwd_win", "msda_fwd_win2", "msda_fwd_win3", "msda_fwd_win4", "msda_fwd_lg3", "msda_fwd_lanegroup"))
 def test_encoder_shaped_reference_fixture_forward(variant, dev, api):
     """Every kernel an encoder-shaped call can take, against the REFERENCE's own output for that shape
     (tests/golden/encshape_s1065_m2.npz, minted by ms_deform_attn_core_pytorch in float64): abs 1e-4."""
@@ -453,6 +479,55 @@ def test_encoder_shaped_reference_fixture_forward(variant, dev, api):
     if variant != "auto":
         assert lib.last_kernel("forward") == variant
     assert float(np.abs(out.cpu().numpy().reshape(g["out"].shape) - g["out"]).max()) < 1e-4
+
+
+def test_regions_backward_with_a_lent_workspace(dev, api, monkeypatch):
+    """include/msda_hip.h: msda_hip_backward_workspace_bytes / msda_hip_backward_ws_f32.  A workspace from PyTorch's allocator
+    (filled with garbage first: its contents are undefined by contract), then one that is too small (the library's own
+    workspace takes over), on a larger call and a smaller one after it -- equal to the call without a lent workspace (which
+    the parity tests hold against the oracle): grad_sampling_loc / grad_attn_weight bitwise, grad_value to the last float bit but
+    for the order in which a region's float64 sums were added (records are filed with atomics)."""
+    from uninext_amd import ext, workloads
+    MSDA, lib = api
+    raw = lib.load() if hasattr(lib, "load") else None
+    levels_big, levels_small = ((40, 52), (20, 26), (10, 13), (5, 7)), ((30, 36), (15, 18), (8, 9), (4, 5))
+    res = {}
+    for name, levels in (("big", levels_big), ("small", levels_small)):
+        x = _inputs("wide", levels, 71, dev)
+        S = x["value"].shape[1]
+        go = torch.randn(2, S, 256, generator=torch.Generator().manual_seed(72)).to(dev)
+        monkeypatch.setattr(ext, "TORCH_WORKSPACE", False)
+        base = _bwd(MSDA, lib, x, go, "msda_bwd_regions")
+        assert lib.last_kernel("backward") == "msda_bwd_regions"
+        need = int(raw.msda_hip_backward_workspace_bytes(2, S, 8, 32, 4, S, 4))
+        assert need > 2 * S * 8 * 16 * 32          # at least one record per sample
+        assert int(raw.msda_hip_backward_workspace_bytes(2, S, 8, 32, 4, 900, 4)) == 0      # decoder-shaped: no workspace
+        assert int(raw.msda_hip_backward_workspace_bytes(2, S, 8, 16, 4, S, 4)) == 0        # other channel counts: none
+        torch.empty(need, dtype=torch.uint8, device=dev).fill_(0xA5)    # what the allocator hands out next is not zero
+        monkeypatch.setattr(ext, "TORCH_WORKSPACE", True)
+        lent = _bwd(MSDA, lib, x, go, "msda_bwd_regions")
+        assert lib.last_kernel("backward") == "msda_bwd_regions"
+        assert float((base[0] - lent[0]).abs().max()) < 1e-6 and torch.equal(base[1], lent[1]) and torch.equal(base[2], lent[2])
+        res[name] = (x, go, base, need)
+    # direct C-ABI calls: a buffer that is too small / misaligned is ignored, not written past
+    x, go, base, need = res["small"]
+    S = x["value"].shape[1]
+    import ctypes
+    lib.set_variant("backward", "msda_bwd_regions")
+    try:
+        for ws_bytes, shift in ((need // 2, 0), (need + 256, 16)):
+            buf = torch.full((need + 512,), 0x5A, dtype=torch.uint8, device=dev)
+            gv, gl, ga = torch.zeros_like(x["value"]), torch.empty_like(x["loc"]), torch.empty_like(x["attn"])
+            rc = raw.msda_hip_backward_ws_f32(go.data_ptr(), x["value"].data_ptr(), x["shapes"].data_ptr(), x["lsi"].data_ptr(),
+                                              x["loc"].data_ptr(), x["attn"].data_ptr(), 2, S, 8, 32, 4, S, 4, gv.data_ptr(),
+                                              gl.data_ptr(), ga.data_ptr(), buf.data_ptr() + shift, ws_bytes,
+                                              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+            assert rc == 0
+            torch.cuda.synchronize()
+            assert float((gv - base[0]).abs().max()) < 1e-6 and torch.equal(gl, base[1]) and torch.equal(ga, base[2])
+            assert bool((buf == 0x5A).all())            # the refused buffer was not touched
+    finally:
+        lib.set_variant("backward", "auto")
 
 
 @pytest.mark.parametrize("variant", ["auto", "msda_bwd_tiled", "msda_bwd_win", "msda_bwd_regions", "msda_bwd_generic"])
@@ -488,7 +563,7 @@ def test_encoder_kernels_on_other_batch_sizes_and_head_counts(heads, batch, dev,
     levels = ((25, 42), (13, 21), (7, 11), (4, 6))
     x = workloads.make_inputs("encoder", "model", batch=batch, levels=levels, heads=heads, seed=50 + heads, device=dev)
     ref = msda_oracle.forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
-    for kernel in ("msda_fwd_win", "msda_fwd_win2", "msda_fwd_win3", "msda_fwd_win4"):
+    for kernel in carried("forward", "msda_fwd_win", "msda_fwd_win2", "msda_fwd_win3", "msda_fwd_win4"):
         out = _fwd(MSDA, lib, x, kernel)
         assert lib.last_kernel("forward") == kernel
         assert float(np.abs(out.cpu().numpy().astype(np.float64) - ref).max()) < 1e-4, kernel
@@ -519,7 +594,7 @@ def test_window_forward_far_path_with_odd_head_counts(heads, flavour, dev, api):
     for levels in (ODD_PYRAMIDS[2], ODD_PYRAMIDS[4]):
         x = workloads.make_inputs("encoder", batch=2, levels=levels, heads=heads, seed=60 + heads, device=dev, **kw)
         ref = msda_oracle.forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
-        for kernel in ("msda_fwd_win", "msda_fwd_win2", "msda_fwd_win3", "msda_fwd_win4"):
+        for kernel in carried("forward", "msda_fwd_win", "msda_fwd_win2", "msda_fwd_win3", "msda_fwd_win4"):
             out = _fwd(MSDA, lib, x, kernel)
             assert lib.last_kernel("forward") == kernel
             assert float(np.abs(out.cpu().numpy().astype(np.float64) - ref).max()) < 1e-4, (levels, heads, kernel)

@@ -82,7 +82,7 @@ msda_bwd_dec(const float* __restrict__ grad_out, const float* __restrict__ value
   // an accumulator receives at most one corner of each level-l sample of the slice: (q1 - q0) * 4 adds of at most
   // max |grad_out| * max |attn| each (bilinear weights <= 1)
   const float bound = (float)(max(q1 - q0, 1) * 4) * __uint_as_float(mt.gmax_bits) * __uint_as_float(mt.amax_bits);
-  const bool use_lds = bound <= 3.402823466e+38f && nslots > 0;          // false for NaN / Inf: everything takes float atomics
+  const bool use_lds = bound < 0x1p120f && nslots > 0;   // false for NaN / Inf and for bounds the clamped exponent below cannot scale into int32 (>= 2^120): float atomics
   float scale = 1.f, inv_scale = 1.f;
   if (use_lds && bound > 0.f) {
     int e;

@@ -342,21 +342,22 @@ int launch_backward_regions(const float* grad_out, const float* value, const int
   int dev = 0;
   if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return (int)e;
   if (dev < 0 || dev >= kMaxDevices) return (int)hipErrorInvalidDevice;
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(stream, &cap) != hipSuccess) (void)hipGetLastError();
-  if (cap != hipStreamCaptureStatusNone)   // no allocation and no cross-stream hand-over inside a capture
-    return launch_backward_tiled(grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, stream);
-
   const size_t b_counts = table_bytes(d), b_recs = record_bytes(d);
   void* const lent = t_call_ws;
   const size_t lent_bytes = t_call_ws_bytes;
   t_call_ws = nullptr;
   t_call_ws_bytes = 0;
+  const bool own = !(lent && lent_bytes >= 3 * b_counts + b_recs && ((uintptr_t)lent & 255) == 0);
+  if (own) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess) (void)hipGetLastError();
+    if (cap != hipStreamCaptureStatusNone)   // no allocation and no cross-stream hand-over inside a capture
+      return launch_backward_tiled(grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, stream);
+  }
   Workspace& ws = g_ws[dev];
   std::unique_lock<std::mutex> lock(ws.mu, std::defer_lock);
   char* base;
   size_t tb;
-  const bool own = !(lent && lent_bytes >= 3 * b_counts + b_recs && ((uintptr_t)lent & 255) == 0);
   if (!own) {
     // the caller's buffer (stream-ordered by the caller's allocator): tables laid out by this call's sizes, nothing survives
     base = static_cast<char*>(lent);

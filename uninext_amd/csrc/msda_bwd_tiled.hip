@@ -293,7 +293,7 @@ __device__ __forceinline__ void bwd_tiled_body(const float* __restrict__ grad_ou
       __syncthreads();
       if (one_round) {
         const float bound = (float)nq * __uint_as_float(mt.gmax_bits) * __uint_as_float(mt.amax_bits);
-        use_lds = bound <= 3.402823466e+38f;            // false for NaN / Inf
+        use_lds = bound < 0x1p120f;                     // false for NaN / Inf, and for bounds the clamped exponent below cannot scale into int32
         if (use_lds && bound > 0.f) {
           int k;
           (void)frexpf(bound, &k);                       // bound < 2^k

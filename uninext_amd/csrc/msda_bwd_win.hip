@@ -308,7 +308,7 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
           const float bound = (float)(kL0Waves * 16 + (int)mt.pad0) * __uint_as_float(mt.gmax_bits) * __uint_as_float(mt.amax_bits);
           // false for NaN / Inf, and for tiles of more than 256 pairs (pyramids with a finer level after the first): every
           // sample then takes the float-atomic path (thousands of roundings per pixel at a coarse scale add up past 1e-4)
-          use_lds = bound <= 3.402823466e+38f && kL0Waves * 16 + (int)mt.pad0 <= 256;
+          use_lds = bound < 0x1p120f && kL0Waves * 16 + (int)mt.pad0 <= 256;   // (>= 2^120: the clamped exponent below could not scale it into int32)
           if (use_lds && bound > 0.f) {
             int e;
             (void)frexpf(bound, &e);                         // bound < 2^e

@@ -24,6 +24,12 @@ _SUFFIX = {torch.float32: "f32", torch.float64: "f64"}
 # reference's error.  GPU tensors never take this route: they go to the HIP kernels or fail loudly.
 STRICT_DEVICE = os.environ.get("MSDA_HIP_STRICT_DEVICE", "0") == "1"
 HOST_THREADS = int(os.environ.get("MSDA_HOST_THREADS", "0"))   # 0: all hardware threads
+# Backward workspace (include/msda_hip.h: msda_hip_backward_workspace_bytes / msda_hip_backward_ws_f32): "1" lends the
+# library a buffer from PyTorch's caching allocator for every fp32 backward call that may need one (stream-ordered, no
+# hipMalloc / device synchronisation inside the library, capturable) at the price of holding ~0.7 GB per encoder-shaped call
+# in the allocator's cache; "0" (default) leaves the library its own per-device workspace, allocated only when
+# msda_bwd_regions is actually chosen.
+TORCH_WORKSPACE = os.environ.get("MSDA_HIP_TORCH_WORKSPACE", "0") == "1"
 
 
 # ---- call context of the automatic forward-kernel choice (include/msda_hip.h: msda_hip_set_call_context) ----------------
@@ -194,11 +200,19 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     grad_attn = torch.empty_like(attn_weight)
     with torch.cuda.device(value.device):
         stream = torch.cuda.current_stream().cuda_stream
+        ws_bytes = int(lib.msda_hip_backward_workspace_bytes(N, S, M, D, L, Lq, P)) if TORCH_WORKSPACE and suf == "f32" else 0
         _set_call_context(lib, value.dtype, spatial_shapes, level_start_index, S, D, L, Lq, P)
-        rc = getattr(lib, "msda_hip_backward_" + suf)(
-            grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
-            sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P, grad_value.data_ptr(),
-            grad_loc.data_ptr(), grad_attn.data_ptr(), ctypes.c_void_p(stream))
+        if ws_bytes > 0:
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=value.device)   # freed (to the cache) in stream order
+            rc = lib.msda_hip_backward_ws_f32(
+                grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P, grad_value.data_ptr(),
+                grad_loc.data_ptr(), grad_attn.data_ptr(), ws.data_ptr(), ws_bytes, ctypes.c_void_p(stream))
+        else:
+            rc = getattr(lib, "msda_hip_backward_" + suf)(
+                grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P, grad_value.data_ptr(),
+                grad_loc.data_ptr(), grad_attn.data_ptr(), ctypes.c_void_p(stream))
     if rc != 0:
         _raise(rc)
     return [grad_value, grad_loc, grad_attn]
