@@ -8,7 +8,7 @@ import torch
 
 from golden_util import load_golden, maskhead_names, max_abs
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("split_bf16_paths")]   # this file is about the opt-in fast paths
 
 
 @pytest.fixture(scope="module")

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("split_bf16_paths")]   # this file is about the opt-in fast paths
 
 
 @pytest.fixture(scope="module")

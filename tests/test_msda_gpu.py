@@ -652,7 +652,7 @@ def test_module_inference_uses_fused_kernel_and_matches_autograd_path(ref_dim, d
     assert q2.grad is not None and torch.isfinite(q2.grad).all()
 
 
-def test_module_under_inference_mode(dev, api):
+def test_module_under_inference_mode(dev, api, split_bf16_paths):
     """torch.inference_mode(): tensors carry no version counter (`_version` raises).  The module -- shapes tensor built
     inside the forward, parameters loaded under inference_mode -- must run as it does under no_grad."""
     from uninext_amd.modules import MSDeformAttn

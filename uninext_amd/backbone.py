@@ -8,6 +8,8 @@ include/patch_embed_hip.h at inference.
 The HIP kernel is forward-only: with autograd recording (training) the layers run the PyTorch-ROCm convolution, which
 is the same arithmetic in fp32 and has a backward.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -35,9 +37,9 @@ def _hip_conv(x, conv, channels_last, exact):
     return ext.patch_embed_forward(x, w.contiguous(), conv.bias, channels_last=channels_last)
 
 
-def patch_conv2d(x, conv, exact=False):
+def patch_conv2d(x, conv, exact=True):
     """`conv(x)` for an nn.Conv2d whose kernel equals its stride (no padding): [B, E, H // k, W // k].  Inference on
-    the GPU: split-bf16 products from cached packed weights (~2e-5 of the output scale; exact=True: exact-fp32 MFMA)."""
+    the GPU: the exact-fp32 MFMA kernel; exact=False opts into split-bf16 products from cached packed weights (~2e-5 of the output scale)."""
     if _use_hip(x, conv):
         return _hip_conv(x, conv, False, exact)
     return conv(x)
@@ -46,7 +48,9 @@ def patch_conv2d(x, conv, exact=False):
 class PatchEmbed(CachedModuleMixin, nn.Module):
     """Image to Patch Embedding (backbone/utils.py:160-186): same constructor, same `proj` parameter names."""
 
-    exact_fp32 = False   # True: exact-fp32 MFMA kernel instead of the split-bf16 path
+    # True (default): exact-fp32 MFMA kernel (bitwise an fmaf chain, the reference's arithmetic); False -- or env
+    # UNINEXT_AMD_SPLIT_BF16=1 -- opts into the split-bf16 path (3 of 4 partial products, ~2e-5 of the output scale, faster)
+    exact_fp32 = os.environ.get("UNINEXT_AMD_SPLIT_BF16", "0") != "1"
 
     def __init__(self, kernel_size=(16, 16), stride=(16, 16), padding=(0, 0), in_chans=3, embed_dim=768):
         super().__init__()

@@ -12,6 +12,8 @@ composition is used that is algebraically the same but also non-materialising: t
 is one batched matmul against the shared feature map.  `use_raft` up-sampling is not covered (USE_RAFT is False in
 every shipped config, uninext/config.py:178).
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -120,10 +122,10 @@ def _packed_weight(conv):
     return packed_weight(conv, _ext.conv3x3_pack_weight)
 
 
-def conv3x3_relu(x, conv, exact=False):
+def conv3x3_relu(x, conv, exact=True):
     """`F.relu(conv(x))` for a 3x3 / padding 1 nn.Conv2d.  Inference on the GPU runs the HIP implicit-GEMM kernels of
-    include/conv3x3_hip.h: by default the split-bf16 path from cached packed weights (~2e-5 of the output scale, inside
-    the 1e-4 parity bound), with exact=True the exact-fp32 MFMA kernel.  PyTorch otherwise (training, CPU, other
+    include/conv3x3_hip.h: the exact-fp32 MFMA kernel by default; exact=False opts into the split-bf16 path from cached packed
+    weights (~2e-5 of the output scale, inside the 1e-4 parity bound).  PyTorch otherwise (training, CPU, other
     dtypes or geometries)."""
     needs_grad = torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad)
     if (not needs_grad and tuple(conv.kernel_size) == (3, 3) and tuple(conv.padding) == (1, 1)
@@ -141,7 +143,9 @@ class MaskHeadSmallConv(CachedModuleMixin, torch.nn.Module):
     `F.relu(self.layN(...))` steps go through conv3x3_relu.  `use_raft` is not covered (False in every shipped
     config, uninext/config.py:178)."""
 
-    exact_fp32 = False   # True: exact-fp32 MFMA kernel instead of the split-bf16 path (slower than MIOpen, see DESIGN.md)
+    # True (default): exact-fp32 MFMA kernel (the reference's arithmetic); False -- or env UNINEXT_AMD_SPLIT_BF16=1 -- opts into
+    # the split-bf16 path (3 of 4 partial products, ~2e-5 of the output scale; the fast one, see DESIGN.md)
+    exact_fp32 = os.environ.get("UNINEXT_AMD_SPLIT_BF16", "0") != "1"
 
     def __init__(self, dim, fpn_dims, context_dim, use_raft=False, up_rate=4):
         super().__init__()

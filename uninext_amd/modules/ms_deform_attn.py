@@ -10,10 +10,12 @@ initialisation (:54-76), argument meaning and errors of `forward` (:79-116).  Th
     reference points and does softmax, location arithmetic and sampling in one pass.
     Set `MSDeformAttn.fuse_prologue = False` (or env UNINEXT_AMD_NO_FUSED=1) to force the two-step path.
 
-The four projections are PyTorch-ROCm GEMMs (hipBLASLt) whenever autograd records; at inference they run
-include/linear_hip.h -- split-bf16 products on the matrix cores from weights packed once per module (~2e-5 of the
-output scale per layer), with the padding-mask fill folded into value_proj's epilogue.
-`MSDeformAttn.fast_linear = False` (or env UNINEXT_AMD_EXACT_LINEAR=1) keeps the fp32 library GEMMs.
+The four projections are fp32 PyTorch-ROCm GEMMs (hipBLASLt), as in the reference -- the DEFAULT.  Opt-in for inference:
+`MSDeformAttn.fast_linear = True` (or env UNINEXT_AMD_SPLIT_BF16=1) runs them through include/linear_hip.h -- split-bf16
+products on the matrix cores (3 of the 4 partial products of a bf16 hi/lo split) from weights packed once per module,
+~2e-5 of the output scale per layer on unit-scale data (tests/test_linear_gpu.py holds the bound at trained-checkpoint
+scales as well), with the padding-mask fill folded into value_proj's epilogue.  Narrower arithmetic than the reference's
+is never the out-of-the-box behaviour.
 """
 import math
 import os
@@ -37,7 +39,7 @@ def _is_power_of_2(n):
 
 class MSDeformAttn(CachedModuleMixin, nn.Module):
     fuse_prologue = os.environ.get("UNINEXT_AMD_NO_FUSED", "0") != "1"
-    fast_linear = os.environ.get("UNINEXT_AMD_EXACT_LINEAR", "0") != "1"
+    fast_linear = os.environ.get("UNINEXT_AMD_SPLIT_BF16", "0") == "1"   # opt-in: split-bf16 projections at inference
 
     def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4):
         super().__init__()
