@@ -60,7 +60,7 @@ def load_reference_matcher():
     return load("refpkg.models.deformable_detr.matcher", os.path.join(UX, "models/deformable_detr/matcher.py"))
 
 
-def make_case(seed, bs, Q, T, gts, duplicate=False, one_token=False):
+def make_case(seed, bs, Q, T, gts, duplicate=False, one_token=False, clustered=False):
     """pred_logits [bs,Q,T], pred_boxes [bs,Q,4] cxcywh in (0,1); targets: boxes [G,4], positive_map [G,T] bool."""
     g = torch.Generator().manual_seed(seed)
     logits = torch.randn(bs, Q, T, generator=g) * 2.0 - 2.0
@@ -72,6 +72,11 @@ def make_case(seed, bs, Q, T, gts, duplicate=False, one_token=False):
         G = gts[b]
         tc = 0.1 + 0.8 * torch.rand(G, 2, generator=g)
         tw = 0.03 + 0.3 * torch.rand(G, 2, generator=g)
+        if clustered:   # many overlapping targets (some identical) fighting for few queries: the repair loop of matcher.py:417-435 runs
+            tc = 0.45 + 0.1 * torch.rand(G, 2, generator=g)
+            tw = 0.2 + 0.05 * torch.rand(G, 2, generator=g)
+            tc[1::3] = tc[0::3][:len(tc[1::3])]
+            tw[1::3] = tw[0::3][:len(tw[1::3])]
         tb = torch.cat([tc, tw], -1)
         pm = torch.zeros(G, T, dtype=torch.bool)
         for k in range(G):
@@ -101,6 +106,7 @@ CASES = {
     "matcher_empty_image": dict(seed=4, bs=3, Q=100, T=256, gts=[4, 0, 1]),
     "matcher_many_gt": dict(seed=5, bs=1, Q=900, T=256, gts=[60]),
     "matcher_encoder_q22223": dict(seed=6, bs=1, Q=22223, T=16, gts=[11], one_token=True),
+    "matcher_ota_conflicts": dict(seed=7, bs=2, Q=120, T=64, gts=[30, 45], clustered=True),
 }
 
 

@@ -83,3 +83,27 @@ def test_matcher_cost_header_symbols_and_argument_errors():
     assert lib.matcher_cost_hip_f32(None, one, one, one, one, 4, 4, 4, 1.0, 1.0, 1.0, one, None) == -1
     assert lib.matcher_cost_hip_f32(None, None, None, None, None, 0, 4, 4, 1.0, 1.0, 1.0, None, None) == 0     # nothing to do
     assert b"matcher_cost" in lib.msda_hip_last_error()
+
+
+def test_ota_header_symbols_and_argument_errors():
+    """include/ota_hip.h: both symbols are exported and the argument checks answer without a GPU."""
+    import ctypes
+    from uninext_amd import _lib
+    text = open(os.path.join(ROOT, "include", "ota_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    assert set(re.findall(r"\b(ota_\w+_hip\w*)\s*\(", text)) == set(_lib.OTA_EXPORTS)
+    assert int(re.search(r"#define OTA_HIP_MAX_BATCH (\d+)", text).group(1)) == _lib.OTA_MAX_BATCH
+    lib = _lib.load()
+    for sym in _lib.OTA_EXPORTS:
+        assert hasattr(lib, sym)
+    one = 16
+    off = (ctypes.c_int32 * 3)(0, 2, 5)
+    assert lib.ota_cost_hip_f32(one, one, one, one, off, 65, 4, 4, one, one, one, None) == -2            # batch > OTA_HIP_MAX_BATCH
+    assert lib.ota_cost_hip_f32(one, one, one, one, None, 2, 4, 4, one, one, one, None) == -1            # no offsets
+    assert lib.ota_cost_hip_f32(None, one, one, one, off, 2, 4, 4, one, one, one, None) == -1
+    assert lib.ota_cost_hip_f32(one, one, one, one, (ctypes.c_int32 * 3)(0, 3, 2), 2, 4, 4, one, one, one, None) == -2   # decreasing
+    assert lib.ota_cost_hip_f32(one, one, one, one, (ctypes.c_int32 * 3)(1, 3, 4), 2, 4, 4, one, one, one, None) == -2   # gt_off[0] != 0
+    assert lib.ota_cost_hip_f32(None, None, None, None, (ctypes.c_int32 * 3)(0, 0, 0), 2, 4, 4, None, None, None, None) == 0   # no targets
+    assert lib.ota_dynamic_k_hip(one, one, one, one, (ctypes.c_int32 * 2)(0, 5000), 1, 4, 10, one, one, one, one, one, None) == -2   # > 4096 targets
+    assert lib.ota_dynamic_k_hip(one, one, one, one, off, 2, 4, 10, one, one, one, None, one, None) == -1
+    assert b"ota" in lib.msda_hip_last_error()

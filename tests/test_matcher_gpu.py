@@ -23,16 +23,147 @@ def test_hungarian_on_device_matches_reference(name, fused):
         assert np.array_equal(i.numpy(), g[f"hung_i_{b}"]) and np.array_equal(j.numpy(), g[f"hung_j_{b}"])
 
 
-@pytest.mark.parametrize("name", [n for n in matcher_names() if "encoder" not in n])
-def test_ota_on_device_matches_reference(name):
+OTA_NAMES = [n for n in matcher_names() if "encoder" not in n]
+
+
+@pytest.mark.parametrize("device_ota", [True, False])
+@pytest.mark.parametrize("name", OTA_NAMES)
+def test_ota_on_device_matches_reference(name, device_ota):
+    """device_ota: the two HIP kernels of include/ota_hip.h; otherwise the PyTorch composition.  Both return the
+    reference matcher's integers on every fixture -- exact ties, an image without targets, the conflict-heavy case."""
     g, bs, outputs, targets = _case(name, device="cuda:0")
-    indices, matched = HungarianMatcherVL(cost_class=2, cost_bbox=5, cost_giou=2).forward_ota(outputs, targets)
+    matcher = HungarianMatcherVL(cost_class=2, cost_bbox=5, cost_giou=2)
+    matcher.device_ota = device_ota
+    indices, matched = matcher.forward_ota(outputs, targets)
     for b in range(bs):
         assert indices[b][0].is_cuda or len(targets[b]["boxes"]) == 0 or indices[b][0].device.type == "cuda"
         assert np.array_equal(indices[b][0].cpu().numpy(), g[f"ota_q_{b}"])
         assert np.array_equal(indices[b][1].cpu().numpy(), g[f"ota_g_{b}"])
         m = matched[b].cpu().numpy() if torch.is_tensor(matched[b]) else np.asarray(matched[b], dtype=np.int64)
         assert np.array_equal(m, g[f"ota_matched_{b}"])
+
+
+def test_ota_device_path_never_synchronises_before_its_one_copy():
+    """zero host syncs until the final index copy.  Everything up to the copy of the per-image counts runs
+    under torch.cuda.set_sync_debug_mode("error") -- any synchronising PyTorch call (nonzero, .item(), boolean-mask
+    indexing, .cpu(), `if tensor:`) raises there; the PyTorch composition, for comparison, does raise."""
+    g, bs, outputs, targets = _case("matcher_q900_t256", device="cuda:0")
+    matcher = HungarianMatcherVL(cost_class=2, cost_bbox=5, cost_giou=2)
+    prob = outputs["pred_logits"].sigmoid()
+    matcher.ota_device_launch(prob, outputs["pred_boxes"], targets)      # warm-up: library load, allocator
+    torch.cuda.synchronize()
+    old = torch.cuda.get_sync_debug_mode()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        sel_q, sel_g, matched, count, status, sizes = matcher.ota_device_launch(prob, outputs["pred_boxes"], targets)
+        matcher.device_ota = False
+        with pytest.raises(RuntimeError):
+            matcher.forward_ota(outputs, targets)                         # the composition synchronises (per-target masks, .any())
+    finally:
+        torch.cuda.set_sync_debug_mode(old)
+    counts = count.cpu().tolist()                                         # the one copy
+    assert status.cpu().tolist() == [0] * bs
+    for b in range(bs):
+        assert np.array_equal(sel_q[b, :counts[b]].cpu().numpy(), g[f"ota_q_{b}"])
+        assert np.array_equal(sel_g[b, :counts[b]].cpu().numpy(), g[f"ota_g_{b}"])
+
+
+@pytest.mark.parametrize("name", OTA_NAMES)
+def test_ota_kernels_against_the_oracle_array_for_array(name):
+    """ota_cost_hip_f32: cost, IoU and prior flags BITWISE the oracle's on the same focal table (the table is PyTorch's on
+    the GPU, copied to the host for the oracle); ota_dynamic_k_hip: the final cost matrix (penalties applied in place), the
+    0 / 1 matching matrix and all index outputs equal to the oracle's."""
+    from oracle import ota_oracle
+    from uninext_amd import ext
+    from uninext_amd.matcher import FOCAL_ALPHA, FOCAL_GAMMA
+    g, bs, outputs, targets = _case(name, device="cuda:0")
+    prob = outputs["pred_logits"].sigmoid()
+    neg = (1 - FOCAL_ALPHA) * (prob ** FOCAL_GAMMA) * (-(1 - prob + 1e-8).log())
+    pos = FOCAL_ALPHA * ((1 - prob) ** FOCAL_GAMMA) * (-(prob + 1e-8).log())
+    table = pos - neg
+    sizes = [len(t["boxes"]) for t in targets]
+    Q = prob.shape[1]
+    tb = torch.cat([t["boxes"] for t in targets])
+    pm = torch.cat([t["positive_map"] for t in targets])
+    # the cost kernel alone (through the C ABI, like ext.ota_assign does)
+    import ctypes
+    lib = ext._lib.load()
+    off = [0]
+    for n in sizes:
+        off.append(off[-1] + n)
+    G = off[-1]
+    cost = torch.empty(Q * G, device="cuda:0")
+    iou = torch.empty(Q * G, device="cuda:0")
+    flags = torch.empty(Q * G, dtype=torch.uint8, device="cuda:0")
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = lib.ota_cost_hip_f32(table.contiguous().data_ptr(), outputs["pred_boxes"].contiguous().data_ptr(), tb.data_ptr(),
+                              pm.view(torch.uint8).data_ptr(), (ctypes.c_int32 * (bs + 1))(*off), bs, Q, prob.shape[2],
+                              cost.data_ptr(), iou.data_ptr(), flags.data_ptr(), stream)
+    assert rc == 0
+    sel_q, sel_g, matched, count, status = ext.ota_assign(table, outputs["pred_boxes"], tb, pm, sizes)
+    counts = count.cpu().tolist()
+    table_h = table.cpu().numpy()
+    for b in range(bs):
+        n = sizes[b]
+        if n == 0:
+            assert counts[b] == 0
+            continue
+        blk = slice(Q * off[b], Q * off[b + 1])
+        o_cost, o_iou, o_flags = ota_oracle.cost_terms(table_h[b], outputs["pred_boxes"][b].cpu().numpy(), targets[b]["boxes"].cpu().numpy(),
+                                                      targets[b]["positive_map"].cpu().numpy())
+        k_cost, k_iou = cost[blk].view(Q, n).cpu().numpy(), iou[blk].view(Q, n).cpu().numpy()
+        assert np.array_equal(k_cost.view(np.uint32), o_cost.view(np.uint32)), float(np.abs(k_cost - o_cost).max())
+        assert np.array_equal(k_iou.view(np.uint32), o_iou.view(np.uint32))
+        assert np.array_equal(flags[blk].view(Q, n).cpu().numpy(), o_flags)
+        sel, gt, o_matched, M, st = ota_oracle.dynamic_k(o_cost, o_iou, o_flags)
+        assert np.array_equal(sel_q[b, :counts[b]].cpu().numpy(), sel) and np.array_equal(sel_g[b, :counts[b]].cpu().numpy(), gt)
+        assert np.array_equal(matched[off[b]:off[b + 1]].cpu().numpy(), o_matched)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_ota_device_on_conflict_heavy_batches(seed):
+    """Random batches of clustered / duplicated targets, 1..3 tokens per class name, an empty image in between, more
+    queries than one pass of the workgroup (Q = 1500): device path == oracle == the reference's per-target loop."""
+    from oracle import ota_oracle
+    from uninext_amd.matcher import FOCAL_ALPHA, FOCAL_GAMMA
+    g = torch.Generator().manual_seed(900 + seed)
+    bs, T = 3, 24
+    Q = 1500 if seed == 0 else 200
+    logits = torch.randn(bs, Q, T, generator=g) * 2
+    boxes = torch.cat([torch.rand(bs, Q, 2, generator=g), 0.03 + 0.3 * torch.rand(bs, Q, 2, generator=g) ** 2], -1)
+    targets = []
+    for b in range(bs):
+        G = 0 if (b == 1 and seed % 2) else int(torch.randint(1, 70, (1,), generator=g))
+        c = 0.4 + 0.2 * torch.rand(G, 2, generator=g)
+        tb = torch.cat([c, 0.1 + 0.2 * torch.rand(G, 2, generator=g)], -1)
+        if G > 4 and seed % 3 == 0:
+            tb[1::4] = tb[0::4][:len(tb[1::4])]
+        pm = torch.zeros(G, T, dtype=torch.bool)
+        for _ in range(1 + seed % 3):
+            pm[torch.arange(G), torch.randint(0, T, (G,), generator=g)] = True
+        targets.append({"boxes": tb.cuda(), "positive_map": pm.cuda()})
+    outputs = {"pred_logits": logits.cuda(), "pred_boxes": boxes.cuda()}
+    m = HungarianMatcherVL(cost_class=2, cost_bbox=5, cost_giou=2)
+    dev_idx, dev_matched = m.forward_ota(outputs, targets)
+    prob = outputs["pred_logits"].sigmoid()
+    neg = (1 - FOCAL_ALPHA) * (prob ** FOCAL_GAMMA) * (-(1 - prob + 1e-8).log())
+    pos = FOCAL_ALPHA * ((1 - prob) ** FOCAL_GAMMA) * (-(prob + 1e-8).log())
+    table = (pos - neg).cpu().numpy()
+    m.device_ota, m.batched_topk = False, False
+    loop_idx, loop_matched = m.forward_ota(outputs, targets)
+    for b in range(bs):
+        n = len(targets[b]["boxes"])
+        if n == 0:
+            assert dev_idx[b][0].numel() == 0 and dev_matched[b] == []
+            continue
+        cost, iou, flags = ota_oracle.cost_terms(table[b], boxes[b].numpy(), targets[b]["boxes"].cpu().numpy(), targets[b]["positive_map"].cpu().numpy())
+        sel, gt, o_matched, M, st = ota_oracle.dynamic_k(cost, iou, flags)
+        assert np.array_equal(dev_idx[b][0].cpu().numpy(), sel) and np.array_equal(dev_idx[b][1].cpu().numpy(), gt)
+        assert np.array_equal(dev_matched[b].cpu().numpy(), o_matched)
+        if seed % 3 != 0:      # without exactly duplicated targets the composition's GPU top-k has no ties to break its own way
+            assert np.array_equal(dev_idx[b][0].cpu().numpy(), loop_idx[b][0].cpu().numpy())
+            assert np.array_equal(dev_idx[b][1].cpu().numpy(), loop_idx[b][1].cpu().numpy())
+            assert np.array_equal(dev_matched[b].cpu().numpy(), loop_matched[b].cpu().numpy())
 
 
 def _ulps(a, b):

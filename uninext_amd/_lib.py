@@ -28,6 +28,8 @@ LINEAR_EXPORTS = ("linear_hip_packed_weight_bytes", "linear_hip_pack_weight_f32"
 LAYERNORM_EXPORTS = ("add_layernorm_hip_f32",)                                 # include/layernorm_hip.h
 LSAP_EXPORTS = ("lsap_hip_workspace_bytes", "lsap_hip_f32", "lsap_hip_batch_f32")   # include/lsap_hip.h
 MATCHER_COST_EXPORTS = ("matcher_cost_hip_f32",)                                # include/matcher_cost_hip.h
+OTA_EXPORTS = ("ota_cost_hip_f32", "ota_dynamic_k_hip")                         # include/ota_hip.h
+OTA_MAX_BATCH = 64
 LSAP_MAX_BATCH = 32
 CONV3X3_EXPORTS = ("conv3x3_hip_f32", "conv3x3_hip_packed_weight_bytes", "conv3x3_hip_pack_weight_f32",
                    "conv3x3_hip_packed_f32", "upsample_add_hip_f32")           # include/conv3x3_hip.h
@@ -83,6 +85,8 @@ def load():
     lib.lsap_hip_batch_f32.argtypes, lib.lsap_hip_batch_f32.restype = [i, p, p, p, p, p, p, p, p, p], i
     f = ctypes.c_float
     lib.matcher_cost_hip_f32.argtypes, lib.matcher_cost_hip_f32.restype = [p, p, p, p, p, i, i, i, f, f, f, p, p], i
+    lib.ota_cost_hip_f32.argtypes, lib.ota_cost_hip_f32.restype = [p, p, p, p, p, i, i, i, p, p, p, p], i
+    lib.ota_dynamic_k_hip.argtypes, lib.ota_dynamic_k_hip.restype = [p, p, p, p, p, i, i, i, p, p, p, p, p, p], i
     lib.dynmask_hip_forward_f32.argtypes = [p, p, p, p, i, i, i, i, i, i, p, p]
     lib.dynmask_hip_forward_f32.restype = i
     lib.aligned_bilinear_hip_f32.argtypes, lib.aligned_bilinear_hip_f32.restype = [p, i, i, i, i, p, p], i

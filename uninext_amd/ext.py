@@ -667,6 +667,54 @@ def matcher_cost(logits, boxes, tgt_boxes, positive_map, w_class, w_bbox, w_giou
     return cost
 
 
+def ota_assign(class_table, boxes, tgt_boxes, positive_map, sizes, max_rounds=10000):
+    """simOTA assignment of a whole batch on the device (include/ota_hip.h): two kernels, nothing returns to the host.
+    class_table [bs, Q, T] fp32 (the focal table pos - neg of matcher.py:327-330), boxes [bs, Q, 4] cxcywh, tgt_boxes
+    [G_total, 4], positive_map [G_total, T] bool / uint8 -- targets of all images concatenated, `sizes` their counts per image
+    (Python ints).  Returns device tensors (sel_query [bs, Q] int64, sel_gt [bs, Q] int64, matched_query [G_total] int64,
+    num_selected [bs] int32, status [bs] int32): image b's assignment is sel_query[b, :num_selected[b]] (ascending) with the
+    target sel_gt[b, :num_selected[b]] each, and matched_query[off_b : off_b + G_b] the cheapest own query of every target."""
+    lib = _lib.load()
+    dev = class_table.device
+    bs, Q, T = class_table.shape
+    if bs > _lib.OTA_MAX_BATCH:
+        raise RuntimeError("ota_assign: at most %d images per call" % _lib.OTA_MAX_BATCH)
+    for name, t, shape in (("class_table", class_table, (bs, Q, T)), ("boxes", boxes, (bs, Q, 4)), ("tgt_boxes", tgt_boxes, (sum(sizes), 4))):
+        if not (t.is_cuda and t.device == dev and t.dtype == torch.float32 and tuple(t.shape) == shape):
+            raise RuntimeError("ota_assign: %s has to be a float32 tensor of shape %s on the GPU of the table" % (name, (shape,)))
+    if tuple(positive_map.shape) != (sum(sizes), T) or positive_map.dtype not in (torch.bool, torch.uint8) or positive_map.device != dev:
+        raise RuntimeError("ota_assign: positive_map has to be [G_total, T] bool / uint8 on the same GPU")
+    class_table, boxes, tgt_boxes = class_table.contiguous(), boxes.contiguous(), tgt_boxes.contiguous()
+    pm = positive_map.contiguous().view(torch.uint8)
+    off = [0]
+    for n in sizes:
+        off.append(off[-1] + int(n))
+    gt_off = (ctypes.c_int32 * (bs + 1))(*off)
+    G = off[-1]
+    cost = torch.empty(Q * G, dtype=torch.float32, device=dev)
+    iou = torch.empty(Q * G, dtype=torch.float32, device=dev)
+    flags = torch.empty(Q * G, dtype=torch.uint8, device=dev)
+    matching = torch.empty(Q * G, dtype=torch.uint8, device=dev)
+    sel_q = torch.empty((bs, Q), dtype=torch.int64, device=dev)
+    sel_g = torch.empty((bs, Q), dtype=torch.int64, device=dev)
+    matched = torch.empty(G, dtype=torch.int64, device=dev)
+    count = torch.empty(bs, dtype=torch.int32, device=dev)
+    status = torch.empty(bs, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        rc = lib.ota_cost_hip_f32(class_table.data_ptr(), boxes.data_ptr(), tgt_boxes.data_ptr() if G else None,
+                                  pm.data_ptr() if G else None, gt_off, bs, Q, T, cost.data_ptr() if G else None,
+                                  iou.data_ptr() if G else None, flags.data_ptr() if G else None, stream)
+        if rc != 0:
+            _raise(rc)
+        rc = lib.ota_dynamic_k_hip(cost.data_ptr() if G else None, iou.data_ptr() if G else None, flags.data_ptr() if G else None,
+                                   matching.data_ptr() if G else None, gt_off, bs, Q, int(max_rounds), sel_q.data_ptr(),
+                                   sel_g.data_ptr(), matched.data_ptr() if G else None, count.data_ptr(), status.data_ptr(), stream)
+        if rc != 0:
+            _raise(rc)
+    return sel_q, sel_g, matched, count, status
+
+
 def lsap_batch(costs, check=True):
     """Linear sum assignment of each 2-d fp32 GPU cost matrix in `costs` (row-major views with any row stride, e.g.
     column slices of one big matrix) on the device, with SciPy's result index for index (include/lsap_hip.h).

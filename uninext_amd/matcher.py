@@ -17,6 +17,19 @@ shortest-augmenting-path algorithm with SciPy's tie rules, index-for-index equal
 only the min(Q, G) index pairs come back to the host; for CPU inputs, or with `device_lsap = False`, it is SciPy's
 `scipy.optimize.linear_sum_assignment` (any SciPy > 1.5.1 as in the reference's setup.py:185) on the host, exactly
 where the reference runs it (matcher.py:499-502).
+
+simOTA (`forward_ota`, the matcher of every decoder layer in the shipped configs): for GPU fp32 inputs (`device_ota =
+True`, the default) the whole batch is assigned by two HIP kernels (include/ota_hip.h, csrc/ota.hip) that follow
+matcher.py:313-447 float operation for float operation and tie rule for tie rule; the focal table `pos - neg` that feeds
+them is formed by the reference's own elementwise PyTorch operations.  Nothing synchronises with the host until the
+selected-query counts are copied back, once per call, to cut the index tensors to their lengths
+(tests/test_matcher_gpu.py asserts that with torch.cuda.set_sync_debug_mode).  CPU inputs and `device_ota = False` run
+the PyTorch composition below -- the reference's data flow with its per-target loops.
+
+`fused_cost` (Hungarian cost matrix in one kernel) evaluates the composition's float32 operations in its order, but its
+logf is this ROCm's device library's, which differs from the one PyTorch was built with by one unit in the last place on a
+third of the arguments: the class term agrees with the composition to 5e-7, not bitwise (tests/test_matcher_gpu.py); the
+assignment of every reference-minted fixture is unchanged.  Set `fused_cost = False` for the composition itself.
 """
 import torch
 from scipy.optimize import linear_sum_assignment
@@ -93,6 +106,7 @@ class HungarianMatcherVL(nn.Module):
     batched_topk = True   # dynamic-k selection without a host sync per ground-truth box (same indices; see the tests)
     device_lsap = True    # GPU inputs: solve the assignment on the device (include/lsap_hip.h) instead of C.cpu() + SciPy
     fused_cost = True     # GPU fp32 inputs: the cost matrix in one kernel (include/matcher_cost_hip.h) instead of ~40 launches
+    device_ota = True     # GPU fp32 inputs: simOTA of the whole batch in two kernels (include/ota_hip.h), one host sync per call
 
     def __init__(self, cost_class: float = 1, cost_bbox: float = 1, cost_giou: float = 1, cost_mask: float = 1):
         super().__init__()
@@ -100,8 +114,8 @@ class HungarianMatcherVL(nn.Module):
         assert cost_class != 0 or cost_bbox != 0 or cost_giou != 0 or cost_mask != 0, "all costs cant be 0"
 
     def cost_matrix(self, logits, boxes, tgt_map, tgt_boxes):
-        """[num_pred, num_gt] cost of matcher.py:476-498.  GPU fp32: one kernel with the composition's own float32
-        operation order (`fused_cost`); otherwise the composition itself."""
+        """[num_pred, num_gt] cost of matcher.py:476-498.  GPU fp32: one kernel with the composition's float32 operation
+        order (`fused_cost`; class term to 1 ulp of logf, see the module docstring); otherwise the composition itself."""
         if (self.fused_cost and logits.is_cuda and logits.dtype == torch.float32 and boxes.dtype == torch.float32
                 and tgt_boxes.dtype == torch.float32 and tgt_boxes.shape[0] > 0 and tgt_map.dtype in (torch.bool, torch.uint8)):
             from . import ext as _ext
@@ -145,6 +159,8 @@ class HungarianMatcherVL(nn.Module):
         bs = outputs["pred_logits"].shape[0]
         prob = outputs["pred_logits"].sigmoid()
         boxes = outputs["pred_boxes"]
+        if self._ota_on_device(prob, boxes, targets):
+            return self._forward_ota_device(prob, boxes, targets, nf)
         indices, matched_ids = [], []
         for b in range(bs):
             cost, ious, gt_boxes = self.compute_cost(b, boxes, prob, targets, nf)
@@ -155,6 +171,48 @@ class HungarianMatcherVL(nn.Module):
                 pair, best_query = (empty, empty.clone()), []
             indices.append(pair)
             matched_ids.append(best_query)
+        return indices, matched_ids
+
+    def _ota_on_device(self, prob, boxes, targets):
+        if not (self.device_ota and prob.is_cuda and prob.dtype == torch.float32 and boxes.dtype == torch.float32
+                and prob.dim() == 3 and 0 < prob.shape[0] <= 64 and prob.shape[1] > 0):
+            return False
+        T = prob.shape[2]
+        for t in targets:
+            pm, tb = t["positive_map"], t["boxes"]
+            if not (pm.is_cuda and pm.dtype in (torch.bool, torch.uint8) and pm.dim() == 2 and pm.shape[1] == T
+                    and tb.is_cuda and tb.dtype == torch.float32 and pm.shape[0] <= 4096):
+                return False      # (index-valued positive maps, other dtypes: the composition)
+        return True
+
+    def ota_device_launch(self, prob, boxes, targets, nf=1):
+        """Everything of forward_ota that runs on the device, WITHOUT the host copy: (sel_query [bs, Q], sel_gt [bs, Q],
+        matched_query [G_total], num_selected [bs], status [bs], sizes) -- see uninext_amd.ext.ota_assign."""
+        from . import ext as _ext
+        neg = (1 - FOCAL_ALPHA) * (prob ** FOCAL_GAMMA) * (-(1 - prob + 1e-8).log())        # matcher.py:329-330, all images at once
+        pos = FOCAL_ALPHA * ((1 - prob) ** FOCAL_GAMMA) * (-(prob + 1e-8).log())
+        table = pos - neg
+        sizes = [len(t["positive_map"]) for t in targets]
+        gt_boxes = torch.cat([t["boxes"].reshape(n, nf, 4)[:, 0] for t, n in zip(targets, sizes)])    # matcher.py:318
+        pm = torch.cat([t["positive_map"] for t in targets])
+        return _ext.ota_assign(table, boxes, gt_boxes, pm, sizes) + (sizes,)
+
+    def _forward_ota_device(self, prob, boxes, targets, nf):
+        sel_q, sel_g, matched, count, status, sizes = self.ota_device_launch(prob, boxes, targets, nf)
+        host = torch.stack((count, status)).cpu()                   # THE host synchronisation of the call
+        counts, stats = host[0].tolist(), host[1].tolist()
+        if any(s != 0 for s in stats):
+            raise RuntimeError("simOTA: the repair loop of matcher.py:417-435 did not terminate (the reference would spin)")
+        indices, matched_ids, off = [], [], 0
+        for b, n in enumerate(sizes):
+            if n > 0:
+                indices.append((sel_q[b, :counts[b]], sel_g[b, :counts[b]]))
+                matched_ids.append(matched[off:off + n])
+            else:
+                empty = torch.tensor([], dtype=torch.int64, device=prob.device)
+                indices.append((empty, empty.clone()))
+                matched_ids.append([])
+            off += n
         return indices, matched_ids
 
     def compute_cost(self, batch_idx, out_bbox, out_prob, targets, nf):
