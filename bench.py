@@ -579,6 +579,16 @@ def main():
             },
         }
         out.update(extras)
+        # multi-GPU readiness: the world size the process group itself reports and, when the DDP leg ran,
+        # the bus bandwidth of its gradient all-reduce -- at the top level of the line
+        rccl_ranks = 1
+        if world > 1:
+            import torch.distributed as dist
+            rccl_ranks = dist.get_world_size()
+        out["rccl_ranks"] = rccl_ranks
+        ddp = extras.get("ddp") if isinstance(extras.get("ddp"), dict) else None
+        out["busbw"] = ddp.get("busbw_GBs") if ddp else None
+        out["busbw_unit"] = "GB/s (2 (n - 1) / n x gradient bytes / all-reduce time; RCCL over xGMI)"
         # the headline is taken on ONE location distribution: say which, how local it is (far fraction reported by the window
         # kernel) and which kernel the call sites settled on; `flavours` holds the launch time on the other two
         ff = extras.get("forward_kernels", {}).get("far_fraction", {}) if isinstance(extras.get("forward_kernels"), dict) else {}

@@ -52,6 +52,11 @@
 namespace msda {
 namespace {
 
+// A/B switch (tools/abl_build.sh): 1 = window-DMA offsets from scalar chunk bases + two per-lane constants (round 4), 0 = per-lane
+// (row, column, inside-the-image, pixel, offset) arithmetic for every DMA instruction.  profiles/r04_forward_instruction_cuts.txt
+#ifndef MSDA_WIN_FASTDMA
+#define MSDA_WIN_FASTDMA 1
+#endif
 constexpr int kT = 512, kWaves = kT / 64, kQuads = kT / 4;
 // auto dispatch (win_forward_auto): the window kernel is used while the last reported far fraction is at most this
 // (bench flavours: far 0.02 -> 78 us against 107 for msda_fwd_lg3, 0.41 -> 147 against 101-123, 0.93 -> 184 against
@@ -381,12 +386,58 @@ __device__ __forceinline__ void win_body(const float* __restrict__ value, const 
         ogx[3] = __builtin_amdgcn_readfirstlane((int)qb<3>((uint32_t)myOx)); ogy[3] = __builtin_amdgcn_readfirstlane((int)qb<3>((uint32_t)myOy));
         const uint32_t chunk = (uint32_t)(lane & 7) * 16u;
         const int sub = lane >> 3;
+        // the wave's number, opaque HERE: what is derived from it (first chunk of a level, LDS destinations, row / column of
+        // a chunk) is a handful of scalar instructions per item -- hoisted out of the item loop as loop invariants those
+        // values do not fit the scalar registers and come back as v_readlane of spilled SGPRs, a vector instruction each
+        int wvs = wv;
+        asm volatile("" : "+s"(wvs));
+#if MSDA_WIN_FASTDMA
+        // Round 4: the byte offset of a lane in a DMA instruction is  (scalar base of the chunk)  +  (slot of the lane within
+        // the chunk) * pitch + piece, and a chunk of 8 consecutive window slots spans at most two window rows -- so the 17
+        // vector instructions of per-lane (row, column, inside-the-image, pixel, offset) arithmetic per DMA instruction become
+        // scalar arithmetic plus ~4 vector instructions: one select between the two rows' bases and one add (and one more
+        // select per out-of-image window column, which only border tiles have).
+        uint32_t vsub = (uint32_t)sub;
+        asm volatile("" : "+v"(vsub));                        // a VGPR: the selects below compare it with scalars
+        const uint32_t vlane = mad_u24(vsub, pixB, chunk);
+#endif
         auto stage_level = [&](auto ltag) __attribute__((always_inline)) {
           constexpr int LV = decltype(ltag)::value;
           constexpr int WW = kWW[LV], C0 = kBase[LV] / 8, C1 = kBase[LV + 1] / 8;
           constexpr int kSteps = (C1 - C0 + kWaves - 1) / kWaves;
           const int Hs = lvH[LV], Ws = lvW[LV], xS = ogx[LV] + lvS[LV], oy = ogy[LV], ox = ogx[LV];
-          int i = C0 + ((wv - C0) & (kWaves - 1));               // this wave's first chunk of the level
+          int i = C0 + ((wvs - C0) & (kWaves - 1));              // this wave's first chunk of the level
+#if MSDA_WIN_FASTDMA
+          if (Ws + 2 >= WW) {                                    // at most ONE window column outside the image on either side
+            // window column 0 is x = -1 / column WW - 1 is x = W  (an int, not a bool: the compiler keeps booleans of uniform
+            // compares as lane masks and re-materialises them through a VGPR at every use)
+            const int border = (int)((uint32_t)ox >> 31) | (int)((uint32_t)(Ws - ox - WW) >> 31);
+#pragma unroll
+            for (int t = 0; t < kSteps; ++t, i += kWaves) {
+              const bool have = i < C1;                           // everything in this loop is wave-uniform except vsub / vlane / off
+              const int rel0 = 8 * (i - C0);
+              const int r0 = rel0 / WW, c0 = rel0 - r0 * WW;      // (division by a constant, scalar)
+              const int thr = WW - c0;                            // lanes with sub >= thr sit in window row r0 + 1
+              const int yA = oy + r0;
+              const bool okA = have && (unsigned)yA < (unsigned)Hs, okB = have && (unsigned)(yA + 1) < (unsigned)Hs;
+              const int pixA = yA * Ws + xS + c0;                 // pixel of slot 0 of the chunk
+              const uint32_t baseA = okA ? (uint32_t)pixA * pixB : kOobOffset;
+              const uint32_t baseB = okB ? (uint32_t)(pixA + Ws - WW) * pixB : kOobOffset;
+              // (mod 2^32: baseA + (baseB - baseA) = baseB; kOobOffset + vlane stays out of range, vlane < 2^31)
+              uint32_t off = (vlane + baseA) + (vsub >= (uint32_t)thr ? baseB - baseA : 0u);
+              if (border != 0) {                                  // border tiles only: a real branch (the asm keeps it from being if-converted)
+                asm volatile("; window column outside the image");
+                if (ox < 0) off = vsub == (uint32_t)(c0 == 0 ? 0 : thr) ? kOobOffset : off;
+                if (ox + WW > Ws) off = vsub == (uint32_t)(WW - 1 - c0) ? kOobOffset : off;   // (wrapped lanes never reach column WW - 1: WW >= 8)
+              }
+              const int dst = have ? i * 1024 : kZeroOff;
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(vsrc, (__attribute__((address_space(3))) void*)(smem + dst), 16,
+                                                       off, hoff, 0, DMA_AUX);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            return;
+          }
+#endif
           int subv = sub;
           asm volatile("" : "+v"(subv));                      // opaque: the level's start is computed HERE
           const int rel = 8 * (i - C0) + subv;                  // slot of this lane in the level's window
