@@ -173,6 +173,35 @@ int msda_hip_forward_fused_hm_f32(const float* value_head_major, const int64_t* 
                                   float* output, void* stream);
 
 /*
+ * Training-side prologue (the autograd half).  The fused forward entry points above take the RAW Linear
+ * outputs; with these two the backward of such a call needs neither sampling_loc nor attn_weight kept from the forward:
+ *
+ *   msda_hip_prologue_f32            sampling_loc [N, Lq, M, L, P, 2] and attn_weight [N, Lq, M, L, P] from reference_points
+ *                                    [N, Lq, L, ref_dim], sampling_offsets [N, Lq, M * L * P * 2] and attn_logits [N, Lq, M * L * P]:
+ *                                    exactly ops/modules/ms_deform_attn.py:99-112 (softmax = exp(x - max) / sum; loc = ref + off /
+ *                                    (W_l, H_l) for ref_dim 2, ref_xy + ((off / P) * ref_wh) * 0.5 for ref_dim 4), one kernel.
+ *   msda_hip_prologue_backward_f32   grad_sampling_offsets and grad_attn_logits from grad_sampling_loc / grad_attn_weight (as
+ *                                    msda_hip_backward_f32 returns them) and the forward's attn_weight: softmax backward
+ *                                    w (g - sum w g) and the location chain rule, one kernel; grad_reference_points [N, Lq, L,
+ *                                    ref_dim] when the pointer is not NULL (a second small kernel, fixed summation order over heads
+ *                                    and points).  grad_sampling_offsets may BE grad_sampling_loc and grad_attn_logits may BE
+ *                                    grad_attn_weight (same sizes; in place).
+ * Device pointers, contiguous fp32, kernels only enqueued on `stream`.  num_levels * num_point <= 64.  uninext_amd.functions.
+ * MSDeformAttnFusedFunction strings them together: forward = msda_hip_forward_fused[_hm]_f32, backward = prologue ->
+ * msda_hip_backward_f32 -> prologue backward.
+ */
+int msda_hip_prologue_f32(const int64_t* spatial_shapes, const float* reference_points, int ref_dim,
+                          const float* sampling_offsets, const float* attn_logits, int batch, int num_heads,
+                          int num_levels, int num_query, int num_point, float* sampling_loc, float* attn_weight,
+                          void* stream);
+int msda_hip_prologue_backward_f32(const int64_t* spatial_shapes, const float* reference_points, int ref_dim,
+                                   const float* sampling_offsets, const float* attn_weight,
+                                   const float* grad_sampling_loc, const float* grad_attn_weight, int batch,
+                                   int num_heads, int num_levels, int num_query, int num_point,
+                                   float* grad_sampling_offsets, float* grad_attn_logits,
+                                   float* grad_reference_points, void* stream);
+
+/*
  * Host-pointer (CPU) variants -- SURVEY.md 8(b)(i).  Same argument order and tensor layouts as the device entry
  * points, but every pointer is HOST memory and the work runs on `num_threads` host threads (<= 0: all hardware
  * threads).  The reference has no CPU implementation (ops/src/cpu/ms_deform_attn_cpu.cpp:17-41 are AT_ERROR stubs and

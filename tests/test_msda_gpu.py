@@ -644,12 +644,22 @@ def test_module_inference_uses_fused_kernel_and_matches_autograd_path(ref_dim, d
             MSDeformAttn.fuse_prologue = True
         assert lib.last_kernel("forward") != "msda_fwd_fused"
     assert float((fused - plain).abs().max()) < 2e-5
-    # with gradients required the module must take the differentiable path
+    # with gradients required the module takes a differentiable path: the fused Function (same forward kernel) by default,
+    # the reference's data flow (PyTorch prologue + MSDeformAttnFunction) with fuse_training_prologue off
     q2 = query.clone().requires_grad_(True)
     out = layer(q2, ref, src, sh, lsi, mask)
-    assert lib.last_kernel("forward") != "msda_fwd_fused"
+    assert lib.last_kernel("forward") == "msda_fwd_fused"
     out.sum().backward()
     assert q2.grad is not None and torch.isfinite(q2.grad).all()
+    MSDeformAttn.fuse_training_prologue = False
+    try:
+        q3 = query.clone().requires_grad_(True)
+        out3 = layer(q3, ref, src, sh, lsi, mask)
+        assert lib.last_kernel("forward") != "msda_fwd_fused"
+        out3.sum().backward()
+    finally:
+        MSDeformAttn.fuse_training_prologue = True
+    assert float((out - out3).abs().max()) < 2e-5 and float((q2.grad - q3.grad).abs().max()) < 1e-4 * max(1.0, float(q3.grad.abs().max()))
 
 
 def test_module_under_inference_mode(dev, api, split_bf16_paths):
@@ -675,3 +685,85 @@ def test_module_under_inference_mode(dev, api, split_bf16_paths):
         c = m2(src, ref, src, sh2, torch.cat((sh2.new_zeros((1,)), sh2.prod(1).cumsum(0)[:-1])), None)
     assert torch.equal(a, b)
     assert float((a - c).abs().max()) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------
+# training-side prologue (include/msda_hip.h: msda_hip_prologue_f32 / msda_hip_prologue_backward_f32, MSDeformAttnFusedFunction)
+
+def _torch_prologue(shapes, ref, offsets, logits, M, P):
+    """ops/modules/ms_deform_attn.py:99-112."""
+    N, Lq = offsets.shape[:2]
+    L = shapes.shape[0]
+    off = offsets.view(N, Lq, M, L, P, 2)
+    w = torch.nn.functional.softmax(logits.view(N, Lq, M, L * P), -1).view(N, Lq, M, L, P)
+    if ref.shape[-1] == 2:
+        wh = torch.stack([shapes[..., 1], shapes[..., 0]], -1)
+        loc = ref[:, :, None, :, None, :] + off / wh[None, None, None, :, None, :]
+    else:
+        loc = ref[:, :, None, :, None, :2] + off / P * ref[:, :, None, :, None, 2:] * 0.5
+    return loc, w
+
+
+@pytest.mark.parametrize("ref_dim", [2, 4])
+@pytest.mark.parametrize("M,L,P", [(8, 4, 4), (3, 2, 5), (1, 1, 2)])
+def test_prologue_kernels_vs_the_pytorch_composition(ref_dim, M, L, P, dev):
+    from uninext_amd import ext
+    g = torch.Generator().manual_seed(7 + M)
+    N, Lq = 2, 333
+    levels = ((30, 41), (15, 21), (8, 11), (4, 6))[:L]
+    shapes = torch.as_tensor(levels, dtype=torch.int64, device=dev)
+    ref = torch.rand(N, Lq, L, ref_dim, generator=g).to(dev)
+    offsets = (torch.randn(N, Lq, M * L * P * 2, generator=g) * 3).to(dev).requires_grad_(True)
+    logits = (torch.randn(N, Lq, M * L * P, generator=g) * 2).to(dev).requires_grad_(True)
+    ref.requires_grad_(True)
+    loc_t, w_t = _torch_prologue(shapes, ref, offsets, logits, M, P)
+    loc, w = ext.msda_prologue(shapes, ref.detach(), offsets.detach(), logits.detach(), M, P)
+    assert loc.shape == loc_t.shape and w.shape == w_t.shape
+    assert float((loc - loc_t).abs().max()) < 1e-6 and float((w - w_t).abs().max()) < 1e-6
+    g_loc = torch.randn(loc.shape, generator=g).to(dev)
+    g_w = torch.randn(w.shape, generator=g).to(dev)
+    want_off, want_logits, want_ref = torch.autograd.grad([loc_t, w_t], [offsets, logits, ref], [g_loc, g_w])
+    g_off, g_logits, g_ref = ext.msda_prologue_backward(shapes, ref.detach(), offsets.detach(), w, g_loc, g_w, need_grad_reference=True)
+    assert g_off.shape == want_off.shape and g_logits.shape == want_logits.shape and g_ref.shape == want_ref.shape
+    assert float((g_off - want_off).abs().max()) < 1e-5 * max(1.0, float(want_off.abs().max()))
+    assert float((g_logits - want_logits).abs().max()) < 1e-5 * max(1.0, float(want_logits.abs().max()))
+    assert float((g_ref - want_ref).abs().max()) < 1e-4 * max(1.0, float(want_ref.abs().max()))      # a sum of M * P float32 terms
+    assert ext.msda_prologue_backward(shapes, ref.detach(), offsets.detach(), w, g_loc, g_w)[2] is None
+
+
+@pytest.mark.parametrize("ref_dim", [2, 4])
+@pytest.mark.parametrize("encoder", [True, False])
+def test_fused_training_function_vs_the_reference_data_flow(ref_dim, encoder, dev, api):
+    """MSDeformAttnFusedFunction (fused forward from the raw tensors; backward = prologue kernel -> operator backward ->
+    prologue backward) against the reference's data flow (PyTorch prologue + MSDeformAttnFunction): outputs and ALL gradients
+    (value, reference points, offsets, logits), on an encoder-sized call (window / gather kernels) and a decoder-sized one."""
+    from uninext_amd.functions import MSDeformAttnFunction, MSDeformAttnFusedFunction
+    from uninext_amd.workloads import level_tensors
+    _, lib = api
+    g = torch.Generator().manual_seed(21)
+    levels = ((40, 53), (20, 27), (10, 14), (5, 7))
+    S = sum(h * w for h, w in levels)
+    N, M, L, P = 2, 8, 4, 4
+    Lq = S if encoder else 300
+    sh, lsi = level_tensors(levels, dev)
+    value = torch.randn(N, S, M, 32, generator=g).to(dev).requires_grad_(True)
+    ref = torch.rand(N, Lq, L, ref_dim, generator=g)
+    if ref_dim == 4:
+        ref[..., 2:] = ref[..., 2:] * 0.3 + 0.05
+    ref = ref.to(dev).requires_grad_(True)
+    offsets = (torch.randn(N, Lq, M * L * P * 2, generator=g) * 2).to(dev).requires_grad_(True)
+    logits = torch.randn(N, Lq, M * L * P, generator=g).to(dev).requires_grad_(True)
+    go = torch.randn(N, Lq, M * 32, generator=g).to(dev)
+    out_f = MSDeformAttnFusedFunction.apply(value, sh, lsi, ref, offsets, logits, P)
+    kernel = lib.last_kernel("forward")
+    assert "fused" in kernel, kernel
+    grads_f = torch.autograd.grad(out_f, [value, ref, offsets, logits], go)
+    loc, w = _torch_prologue(sh, ref, offsets, logits, M, P)
+    out_r = MSDeformAttnFunction.apply(value, sh, lsi, loc, w, 64)
+    grads_r = torch.autograd.grad(out_r, [value, ref, offsets, logits], go)
+    assert float((out_f - out_r).abs().max()) < 1e-4
+    for name, a, b in zip(("value", "reference_points", "offsets", "logits"), grads_f, grads_r):
+        scale = max(1.0, float(b.abs().max()))
+        err = float((a - b).abs().max())
+        print("%-16s max |fused - reference flow| %.2e (scale %.1f)" % (name, err, scale))
+        assert err < 2e-4 * scale, (name, err, scale)

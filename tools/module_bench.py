@@ -70,6 +70,35 @@ def main():
             print("%-18s whole layer %8.1f us   prologue+sampling %8.1f us" % ("fused" if fuse else "two-step", whole, part))
     MSDeformAttn.fuse_prologue = True
 
+    # training: forward + backward of the layer (all parameters and the inputs require a gradient) -- the fused Function against
+    # the reference's data flow (PyTorch prologue + MSDeformAttnFunction); peak memory of one step beside the time
+    train = MSDeformAttn(256, 4, 8, 4).to(dev).train()
+    with torch.no_grad():
+        train.sampling_offsets.weight.normal_(0, 0.01)
+        train.attention_weights.weight.normal_(0, 0.1)
+    q_t = [q.clone().requires_grad_(True) for q in queries]
+    s_t = [t.clone().requires_grad_(True) for t in srcs]
+    go = torch.randn(N, S, 256, device=dev)
+
+    def train_step():
+        k = turn[0] % args.rotate
+        turn[0] += 1
+        out = train(q_t[k], ref, s_t[k], sh, lsi, None)
+        out.backward(go)
+    for fused in (True, False, True, False):
+        MSDeformAttn.fuse_training_prologue = fused
+        for t_ in list(train.parameters()) + q_t + s_t:
+            t_.grad = None
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        t = timeit(train_step, max(args.reps // 3, 5))
+        peak = (torch.cuda.max_memory_allocated() - base) / 2 ** 20
+        print("training %-34s forward + backward %8.1f us   peak extra memory %7.1f MiB" % (
+            "MSDeformAttnFusedFunction" if fused else "PyTorch prologue + Function", t, peak))
+    MSDeformAttn.fuse_training_prologue = True
+
 
 if __name__ == "__main__":
     main()

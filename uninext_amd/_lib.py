@@ -16,6 +16,7 @@ EXPORTS = (
     "msda_hip_set_variant", "msda_hip_get_variant", "msda_hip_variant_name", "msda_hip_last_kernel",
     "msda_hip_forward_locality", "msda_hip_set_call_context",
     "msda_hip_backward_workspace_bytes", "msda_hip_backward_ws_f32", "msda_host_last_num_threads",
+    "msda_hip_prologue_f32", "msda_hip_prologue_backward_f32",
 )
 
 DYNMASK_EXPORTS = ("dynmask_hip_forward_f32", "aligned_bilinear_hip_f32", "dynmask_hip_set_variant",
@@ -61,6 +62,9 @@ def load():
         gh = getattr(lib, "msda_host_backward_" + suf)
         gh.argtypes, gh.restype = [p, p, p, p, p, p, i, i, i, i, i, i, i, p, p, p, i], i
     lib.msda_host_last_num_threads.argtypes, lib.msda_host_last_num_threads.restype = [], i
+    lib.msda_hip_prologue_f32.argtypes, lib.msda_hip_prologue_f32.restype = [p, p, i, p, p, i, i, i, i, i, p, p, p], i
+    lib.msda_hip_prologue_backward_f32.argtypes = [p, p, i, p, p, p, p, i, i, i, i, i, p, p, p, p]
+    lib.msda_hip_prologue_backward_f32.restype = i
     lib.msda_hip_backward_workspace_bytes.argtypes, lib.msda_hip_backward_workspace_bytes.restype = [i] * 7, ctypes.c_size_t
     lib.msda_hip_backward_ws_f32.argtypes = [p, p, p, p, p, p, i, i, i, i, i, i, i, p, p, p, p, ctypes.c_size_t, p]
     lib.msda_hip_backward_ws_f32.restype = i

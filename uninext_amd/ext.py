@@ -267,6 +267,55 @@ def ms_deform_attn_forward_fused(value, spatial_shapes, level_start_index, refer
 
 
 # ---- dynamic mask head (include/dynmask_hip.h) -------------------------------------------------------------
+def msda_prologue(spatial_shapes, reference_points, sampling_offsets, attention_logits, num_heads, num_points):
+    """(sampling_locations [N, Lq, M, L, P, 2], attention_weights [N, Lq, M, L, P]) from the raw Linear outputs and the reference
+    points -- ops/modules/ms_deform_attn.py:99-112 in one kernel (include/msda_hip.h: msda_hip_prologue_f32).  fp32, GPU."""
+    lib = _lib.load()
+    N, Lq = sampling_offsets.shape[:2]
+    L, M, P = spatial_shapes.shape[0], int(num_heads), int(num_points)
+    for name, t in (("reference_points", reference_points), ("sampling_offsets", sampling_offsets), ("attention_logits", attention_logits)):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.device == sampling_offsets.device):
+            raise RuntimeError("msda_prologue: %s must be a contiguous float32 tensor on the GPU" % name)
+    if sampling_offsets.numel() != N * Lq * M * L * P * 2 or attention_logits.numel() != N * Lq * M * L * P \
+            or tuple(reference_points.shape[:3]) != (N, Lq, L) or reference_points.shape[-1] not in (2, 4):
+        raise RuntimeError("msda_prologue: inconsistent shapes")
+    loc = torch.empty((N, Lq, M, L, P, 2), dtype=torch.float32, device=sampling_offsets.device)
+    attn = torch.empty((N, Lq, M, L, P), dtype=torch.float32, device=sampling_offsets.device)
+    with torch.cuda.device(sampling_offsets.device):
+        rc = lib.msda_hip_prologue_f32(spatial_shapes.data_ptr(), reference_points.data_ptr(), int(reference_points.shape[-1]),
+                                       sampling_offsets.data_ptr(), attention_logits.data_ptr(), N, M, L, Lq, P, loc.data_ptr(),
+                                       attn.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc != 0:
+        _raise(rc)
+    return loc, attn
+
+
+def msda_prologue_backward(spatial_shapes, reference_points, sampling_offsets, attention_weights, grad_loc, grad_attn,
+                           need_grad_reference=False, inplace=False):
+    """(grad_sampling_offsets, grad_attention_logits, grad_reference_points | None) -- the backward of msda_prologue in one kernel
+    (+ one small one for the reference points).  Shapes as the raw tensors: [N, Lq, M*L*P*2], [N, Lq, M*L*P], [N, Lq, L, 2|4].
+    inplace: the results overwrite grad_loc / grad_attn (returned as views of the raw shapes)."""
+    lib = _lib.load()
+    N, Lq, M, L, P = attention_weights.shape
+    for name, t in (("reference_points", reference_points), ("sampling_offsets", sampling_offsets), ("attention_weights", attention_weights),
+                    ("grad_loc", grad_loc), ("grad_attn", grad_attn)):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.device == attention_weights.device):
+            raise RuntimeError("msda_prologue_backward: %s must be a contiguous float32 tensor on the GPU" % name)
+    dev = attention_weights.device
+    g_off = grad_loc.view(N, Lq, M * L * P * 2) if inplace else torch.empty((N, Lq, M * L * P * 2), dtype=torch.float32, device=dev)
+    g_logits = grad_attn.view(N, Lq, M * L * P) if inplace else torch.empty((N, Lq, M * L * P), dtype=torch.float32, device=dev)
+    g_ref = torch.empty_like(reference_points) if need_grad_reference else None
+    with torch.cuda.device(dev):
+        rc = lib.msda_hip_prologue_backward_f32(
+            spatial_shapes.data_ptr(), reference_points.data_ptr(), int(reference_points.shape[-1]), sampling_offsets.data_ptr(),
+            attention_weights.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(), N, M, L, Lq, P, g_off.data_ptr(),
+            g_logits.data_ptr(), g_ref.data_ptr() if g_ref is not None else None,
+            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc != 0:
+        _raise(rc)
+    return g_off, g_logits, g_ref
+
+
 def dynmask_supported(mask_feats):
     return mask_feats.is_cuda and mask_feats.dtype == torch.float32 and mask_feats.dim() == 4 and mask_feats.shape[1] == 8
 

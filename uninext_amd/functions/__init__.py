@@ -1,1 +1,1 @@
-from .ms_deform_attn_func import MSDeformAttnFunction  # noqa: F401
+from .ms_deform_attn_func import MSDeformAttnFunction, MSDeformAttnFusedFunction  # noqa: F401

@@ -37,3 +37,46 @@ class MSDeformAttnFunction(Function):
             grad_value, grad_loc, grad_attn = MSDA.ms_deform_attn_backward(
                 value, shapes, level_start, locations, weights, grad_output.contiguous(), ctx.im2col_step)
         return grad_value, None, None, grad_loc, grad_attn, None
+
+
+class MSDeformAttnFusedFunction(Function):
+    """`apply(value, spatial_shapes, level_start_index, reference_points, sampling_offsets, attention_logits, num_points)`:
+    MSDeformAttn's prologue AND the operator as one differentiable function (training side).
+
+    forward   msda_hip_forward_fused_f32: softmax, sampling locations and sampling in one kernel from the RAW Linear outputs --
+              `sampling_locations` (45.5 MB per encoder call at N = 2) and the softmaxed weights are never written.
+    backward  recomputes them (msda_hip_prologue_f32, the reference's operations in the reference's order,
+              ops/modules/ms_deform_attn.py:99-112), runs msda_hip_backward_f32 -- the same kernels MSDeformAttnFunction uses
+              -- and maps grad_sampling_loc / grad_attn_weight back onto the raw tensors (msda_hip_prologue_backward_f32:
+              softmax backward + the location chain rule, and the reference points' gradient when they require one).
+    What is saved for backward: value and the raw tensors, which autograd keeps alive anyway as outputs of the Linears.
+    fp32, GPU, 32 channels per head, levels * points == 16 (uninext_amd.ext.fused_forward_supported)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, reference_points, sampling_offsets,
+                attention_logits, num_points):
+        ctx.num_points = int(num_points)
+        ctx.call_site = MSDA.current_call_site()
+        value, reference_points = value.contiguous(), reference_points.contiguous()
+        sampling_offsets, attention_logits = sampling_offsets.contiguous(), attention_logits.contiguous()
+        output = MSDA.ms_deform_attn_forward_fused(value, value_spatial_shapes, value_level_start_index, reference_points,
+                                                   sampling_offsets, attention_logits, ctx.num_points)
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, reference_points, sampling_offsets,
+                              attention_logits)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, grad_output):
+        value, shapes, level_start, ref, offsets, logits = ctx.saved_tensors
+        M = value.shape[2]
+        locations, weights = MSDA.msda_prologue(shapes, ref, offsets, logits, M, ctx.num_points)
+        with MSDA.call_site(ctx.call_site):
+            grad_value, grad_loc, grad_attn = MSDA.ms_deform_attn_backward(
+                value, shapes, level_start, locations, weights, grad_output.contiguous(), 64)
+        del locations                                       # 45.5 MB per encoder call: not needed behind the operator's backward
+        g_off, g_logits, g_ref = MSDA.msda_prologue_backward(shapes, ref, offsets, weights, grad_loc, grad_attn,
+                                                              need_grad_reference=ctx.needs_input_grad[3], inplace=True)
+        return grad_value, None, None, g_ref, g_off, g_logits, None

@@ -4,8 +4,10 @@ Host-side mirror of the reference's ops/modules/ms_deform_attn.py:30-116: same c
 names (`sampling_offsets`, `attention_weights`, `value_proj`, `output_proj` -- reference checkpoints load unchanged),
 initialisation (:54-76), argument meaning and errors of `forward` (:79-116).  The sampling runs in libmsda_hip.so:
 
-  * when gradients are needed: softmax + sampling locations in PyTorch, then `MSDeformAttnFunction` (autograd),
-    exactly the reference's data flow;
+  * when gradients are needed: `MSDeformAttnFusedFunction` -- the fused forward kernel on the raw Linear outputs, and a
+    backward that recomputes locations / weights in one kernel, runs the operator's backward kernels and maps the
+    gradients back in one more (`fuse_training_prologue`, default on; off or unsupported geometry: softmax + sampling
+    locations in PyTorch, then `MSDeformAttnFunction`, exactly the reference's data flow);
   * otherwise (inference): `ms_deform_attn_forward_fused` -- the kernel takes the raw Linear outputs and the
     reference points and does softmax, location arithmetic and sampling in one pass.
     Set `MSDeformAttn.fuse_prologue = False` (or env UNINEXT_AMD_NO_FUSED=1) to force the two-step path.
@@ -28,7 +30,7 @@ from torch.nn.init import constant_, xavier_uniform_
 
 from .. import ext as MSDA
 from .._cache import CachedModuleMixin, CheckedOnce, packed_weight, packed_weight_pair
-from ..functions import MSDeformAttnFunction
+from ..functions import MSDeformAttnFunction, MSDeformAttnFusedFunction
 
 
 def _is_power_of_2(n):
@@ -39,6 +41,9 @@ def _is_power_of_2(n):
 
 class MSDeformAttn(CachedModuleMixin, nn.Module):
     fuse_prologue = os.environ.get("UNINEXT_AMD_NO_FUSED", "0") != "1"
+    # training: MSDeformAttnFusedFunction (fused forward from the raw Linear outputs; backward recomputes the locations / weights
+    # and runs the operator's backward kernels) instead of the PyTorch prologue + MSDeformAttnFunction
+    fuse_training_prologue = os.environ.get("UNINEXT_AMD_NO_FUSED_TRAINING", "0") != "1"
     fast_linear = os.environ.get("UNINEXT_AMD_SPLIT_BF16", "0") == "1"   # opt-in: split-bf16 projections at inference
 
     def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4):
@@ -229,6 +234,12 @@ class MSDeformAttn(CachedModuleMixin, nn.Module):
             elif self._can_fuse(value, reference_points, offsets, logits):
                 sampled = MSDA.ms_deform_attn_forward_fused(value, input_spatial_shapes, input_level_start_index,
                                                             reference_points, offsets, logits, self.n_points)
+            elif (self.fuse_prologue and self.fuse_training_prologue
+                  and MSDA.fused_forward_supported(value, reference_points, self.n_levels, self.n_points)
+                  and query.dtype == torch.float32 and not torch.is_autocast_enabled()):
+                # autograd records: the same fused forward, differentiable (training side)
+                sampled = MSDeformAttnFusedFunction.apply(value, input_spatial_shapes, input_level_start_index,
+                                                          reference_points, offsets, logits, self.n_points)
             else:
                 sampled = self._sample_autograd(value, input_spatial_shapes, input_level_start_index, reference_points,
                                                 offsets, logits)
