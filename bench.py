@@ -38,6 +38,11 @@ Extra objects on the JSON line (all measured in this run, after the timed region
   ddp           world > 1 only: the DDP gradient exchange of config 5 -- fp32 all-reduce(mean) of 0.64 GB of
                 gradients in 25 MB buckets over RCCL (detectron2/engine/defaults.py:380-381 wraps the model
                 in DistributedDataParallel): alone, and overlapped with the backward launches on a side stream.
+  model_slice   SURVEY.md 8(d) model-level accounting: the GPU-resident callers this repository has built (6 encoder layers, 6
+                decoder MSDeformAttn cross-attentions, static + dynamic mask heads) strung together for one bs = 2 inference
+                step: ms per part, frames/s of the slice (an UPPER bound on the model: the backbone and the rest are plain
+                PyTorch-ROCm), and the share of it that the step's sampling kernels are.  rccl_ranks / busbw (top level): the
+                world size the process group reports and the DDP leg's bus bandwidth.
   cpu_baseline  the reference's CPU path (ms_deform_attn_core_pytorch, restated in oracle/msda_gridsample.py)
                 timed on this box's host cores on a bounded sample, rank 0 at N = 1 only.
 """
@@ -75,7 +80,7 @@ def parse_args():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the flavours / backward / train_step / ddp measurements (profiling passes)")
     ap.add_argument("--extras-only", default="",
-                    help="comma list of extras to run (flavours,backward,train,ddp); default all")
+                    help="comma list of extras to run (flavours,backward,train,ddp,slice); default all")
     return ap.parse_args()
 
 
@@ -434,6 +439,85 @@ def measure_ddp(enc, dec, world, reps=5):
             "op_fwd_bwd_ms": st, "overlapped_ms": ov, "backend": "nccl (RCCL over xGMI)"}
 
 
+def measure_model_slice(reps=6):
+    """SURVEY.md 8(d) "model-level accounting": the GPU-resident callers of the path that this repository has built, strung
+    together the way one bs = 2 inference step of the R50 det + seg model runs them -- six encoder layers (self-attention =
+    MSDeformAttn on S = 22223 tokens, FFN, norms), six decoder cross-attentions (MSDeformAttn module, 900 queries), the static
+    mask head (five 3x3 convolutions at 100 x 167) and the dynamic mask head (900 instances per image + two 2x up-samplings).
+    NOT the whole model: the ResNet-50 backbone, the decoder's self-attention / FFN, the heads and the post-processing are
+    plain PyTorch-ROCm modules that this repository does not replace -- so `frames_per_s_slice` is an UPPER bound on the model
+    and `msda_share` says how much of even this slice the sampling kernels are.  Default (exact fp32) arithmetic of the
+    modules, and the opt-in split-bf16 projections / convolutions beside it."""
+    from uninext_amd import ext as _ext
+    from uninext_amd.mask_head import MaskHeadSmallConv
+    from uninext_amd.modules import DeformableTransformerEncoderLayer, MSDeformAttn
+    dev = "cuda"
+    g = torch.Generator().manual_seed(11)
+    levels = workloads.R50_LEVELS_INFER
+    S_ = sum(h * w for h, w in levels)
+    N = BATCH
+    enc_layers = [DeformableTransformerEncoderLayer().to(dev).eval() for _ in range(ENC_LAYERS)]
+    dec_attn = [MSDeformAttn(256, 4, 8, 4).to(dev).eval() for _ in range(DEC_LAYERS)]
+    with torch.no_grad():
+        for m in [l.self_attn for l in enc_layers] + dec_attn:
+            m.sampling_offsets.weight.normal_(0, 0.01)
+            m.attention_weights.weight.normal_(0, 0.1)
+    head = MaskHeadSmallConv(256, None, 256).to(dev).eval()
+    src = torch.randn(N, S_, 256, generator=g).to(dev)
+    pos = (torch.randn(N, S_, 256, generator=g) * 0.3).to(dev)
+    ref = workloads.encoder_reference_points(levels, dev)[None, :, None, :].expand(N, S_, 4, 2).contiguous()
+    sh, lsi = workloads.level_tensors(levels, dev)
+    tgt = torch.randn(N, 900, 256, generator=g).to(dev)
+    ref_dec = torch.rand(N, 900, 4, 4, generator=g).to(dev)
+    ref_dec[..., 2:] = ref_dec[..., 2:] * 0.3 + 0.05
+    feats = [torch.randn(N, 256, h, w, generator=g).to(dev) for h, w in levels[:3]]
+    n_inst = [900] * N
+    inst_xy = (torch.rand(sum(n_inst), 2, generator=g) * torch.tensor([levels[0][1] * 8.0, levels[0][0] * 8.0])).to(dev)
+    inst_params = (torch.randn(sum(n_inst), 169, generator=g) * 0.3).to(dev)
+
+    def timed(fn):
+        with torch.no_grad():
+            fn(); fn()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(reps):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps
+
+    def encoder():
+        x = src
+        for l in enc_layers:
+            x = l(x, pos, ref, sh, lsi, None)
+        return x
+
+    def decoder():
+        return [m(tgt, ref_dec, src, sh, lsi, None) for m in dec_attn]
+
+    def masks():
+        mf = head(feats, None)                                              # [N, 8, 100, 167]
+        logits = _ext.dynmask_forward(mf, inst_xy, inst_params, n_inst, 8, True)
+        up = _ext.aligned_bilinear_forward(logits.reshape(-1, 1, levels[0][0], levels[0][1]), 2)
+        return _ext.aligned_bilinear_forward(up, 2)
+
+    out = {}
+    old = (MSDeformAttn.fast_linear, MaskHeadSmallConv.exact_fp32)
+    try:
+        for name, fast in (("fp32_default", False), ("split_bf16_opt_in", True)):
+            MSDeformAttn.fast_linear, MaskHeadSmallConv.exact_fp32 = fast, not fast
+            e, dd, mk = timed(encoder), timed(decoder), timed(masks)
+            total = e + dd + mk
+            out[name] = {"encoder_6_layers_ms": e, "decoder_cross_attn_6_ms": dd, "mask_heads_ms": mk, "total_ms": total,
+                         "frames_per_s_slice": BATCH / (total * 1e-3)}
+    finally:
+        MSDeformAttn.fast_linear, MaskHeadSmallConv.exact_fp32 = old
+    out["covers"] = ("6 encoder layers + 6 decoder MSDeformAttn cross-attentions + static mask head + dynamic mask head with "
+                     "2 x 2 up-samplings, bs %d inference; NOT the backbone, decoder self-attention / FFN, heads, post-processing" % BATCH)
+    return out
+
+
 def cpu_baseline(flavour):
     """Bounded sample of the same workload on the host: one encoder call and one decoder call of the
     reference's grid_sample path (N = 2); a step is 6 of each.  grid_sample's OpenMP scaling collapses when
@@ -515,7 +599,7 @@ def main():
     elapsed = max_over_ranks(time.perf_counter() - t0, world)
 
     extras = {}
-    want = set(args.extras_only.split(",")) if args.extras_only else {"flavours", "backward", "train", "ddp"}
+    want = set(args.extras_only.split(",")) if args.extras_only else {"flavours", "backward", "train", "ddp", "slice"}
     if not args.no_extras:   # every rank takes part (collectives inside), rank 0 reports
         def extra(key, fn):      # an extra that fails must not take the contract line with it
             try:
@@ -541,6 +625,8 @@ def main():
             extra("train_step", lambda: measure_train_step(tenc6, tdec6, world))
         if "ddp" in want and world > 1:
             extra("ddp", lambda: measure_ddp(tenc6, tdec6, world))
+        if "slice" in want and rank == 0:
+            extra("model_slice", measure_model_slice)
 
     if rank == 0:
         sampled = events[::EVENT_EVERY]
@@ -579,6 +665,9 @@ def main():
             },
         }
         out.update(extras)
+        ms = extras.get("model_slice")
+        if isinstance(ms, dict) and "fp32_default" in ms:    # how much of the GPU-resident slice the step's sampling kernels are
+            ms["msda_share_of_slice"] = (1e3 * elapsed / args.steps) / ms["fp32_default"]["total_ms"]
         # multi-GPU readiness: the world size the process group itself reports and, when the DDP leg ran,
         # the bus bandwidth of its gradient all-reduce -- at the top level of the line
         rccl_ranks = 1
