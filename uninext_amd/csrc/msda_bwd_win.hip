@@ -94,11 +94,6 @@ __device__ __forceinline__ float quad_sum(float v) {   // over the 4 lanes of a 
   v += dppf<0x4E>(v);                                  // quad_perm [2,3,0,1]
   return v;
 }
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
@@ -238,9 +233,6 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
     const __amdgpu_buffer_rsrc_t vsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(value) + img_val, 0, (int)((uint32_t)d.S * pixB), 0x00020000);
     char* const gv_head = reinterpret_cast<char*>(grad_value + img_val) + hoff;   // + pixel byte offset + channel * 4
-    const int tile_ = itemc - b * ntiles;
-    const int ty = to_sgpr((int)(((float)tile_ + 0.5f) * __builtin_amdgcn_rcpf((float)TX)));
-    const int tx = tile_ - ty * TX;
     const bool l0 = wv < kL0Waves;
 
 
