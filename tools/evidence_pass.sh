@@ -1,6 +1,6 @@
 #!/bin/bash
 # The round's evidence pass (GPU box): bench line, rocprofv3 kernel traces of the bench, PMC traffic + SQ counters of the contract
-# launches, kbench tables.  Everything lands under gpurun_out/ev/; copy what is to be judged into profiles/.
+# launches, kbench tables, the caller-side benches.  Everything lands under gpurun_out/ev/; copy what is to be judged into profiles/.
 cd $GRAFT_REPO_ROOT
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/ev
@@ -13,10 +13,12 @@ timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
 ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace_noextras -- python $R/bench.py --no-cpu-baseline --no-extras > $O/trace_noextras.json 2> $O/trace_noextras.err )
 python tools/rocprof_summary.py trace $(find $O/trace_noextras -name "*_results.db" | head -1) > $O/bench_kernel_trace_noextras.txt 2>&1
 cat $O/trace_noextras.json >> $O/bench_kernel_trace_noextras.txt
-( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace_full -- python $R/bench.py --no-cpu-baseline > $O/trace_full.json 2> $O/trace_full.err )
+( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace_full -- python $R/bench.py --no-cpu-baseline --extras-only flavours,backward,train > $O/trace_full.json 2> $O/trace_full.err )
 python tools/rocprof_summary.py trace $(find $O/trace_full -name "*_results.db" | head -1) > $O/bench_kernel_trace.txt 2>&1
 cat $O/trace_full.json >> $O/bench_kernel_trace.txt
-timeout 600 python tools/kbench.py --reps 18 --rotate 6 --variants-fwd 7,9,10,11,12 --variants-bwd 3,4,5,6 --flavours model,wide,uniform > $O/kbench_final.txt 2>&1
+timeout 600 python tools/kbench.py --reps 18 --rotate 6 --variants-fwd 7,9 --variants-bwd 3,4,5,6 --flavours model,wide,uniform > $O/kbench_final.txt 2>&1
 timeout 900 python tools/kbench.py --reps 12 --rotate 3 --workloads all --flavours model,wide > $O/kbench_workloads.txt 2>&1
+timeout 200 python tools/ota_bench.py > $O/ota_bench.txt 2>&1
+timeout 200 python tools/module_bench.py --reps 30 --rotate 3 > $O/module_bench.txt 2>&1
 rm -rf $O/trace_noextras $O/trace_full $O/traffic_prof
 ls -la $O
