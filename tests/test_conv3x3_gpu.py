@@ -78,9 +78,9 @@ def test_full_size_r50_head(dev):
     x = [torch.randn(2, 256, h, w, device=dev) for h, w in ((100, 167), (50, 84), (25, 42))]
     with torch.no_grad():
         out = head(x, None)                                          # HIP route: split-bf16 from packed weights
-        head.exact_fp32 = True
+        head.exact_fp32, head.exact_impl = True, "mfma"
         out_exact = head(x, None)                                    # HIP route: exact-fp32 MFMA
-        head.exact_fp32 = False
+        head.exact_fp32, head.exact_impl = False, None
         F = torch.nn.functional
         f = F.relu(head.lay3(x[-1]))
         f = F.relu(head.lay4(x[-2] + F.interpolate(f, size=x[-2].shape[-2:], mode="nearest")))
@@ -110,12 +110,12 @@ def test_stream_graph_and_autograd_route(dev):
         want = torch.relu(conv(x))
         s = torch.cuda.Stream()
         with torch.cuda.stream(s):
-            a = conv3x3_relu(x, conv)
+            a = conv3x3_relu(x, conv, True, "mfma")       # this library's exact-fp32 kernel (the default exact route is MIOpen)
         s.synchronize()
         assert float((a - want).abs().max()) < 1e-4
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            static_out = conv3x3_relu(x, conv)
+            static_out = conv3x3_relu(x, conv, False)     # the split-bf16 kernel from packed weights
         x.copy_(torch.randn_like(x))
         graph.replay()
         torch.cuda.synchronize()

@@ -122,12 +122,20 @@ def _packed_weight(conv):
     return packed_weight(conv, _ext.conv3x3_pack_weight)
 
 
-def conv3x3_relu(x, conv, exact=True):
-    """`F.relu(conv(x))` for a 3x3 / padding 1 nn.Conv2d.  Inference on the GPU runs the HIP implicit-GEMM kernels of
-    include/conv3x3_hip.h: the exact-fp32 MFMA kernel by default; exact=False opts into the split-bf16 path from cached packed
-    weights (~2e-5 of the output scale, inside the 1e-4 parity bound).  PyTorch otherwise (training, CPU, other
-    dtypes or geometries)."""
+EXACT_CONV_IMPL = os.environ.get("UNINEXT_AMD_EXACT_CONV", "library")   # "library" | "mfma"
+
+
+def conv3x3_relu(x, conv, exact=True, exact_impl=None):
+    """`F.relu(conv(x))` for a 3x3 / padding 1 nn.Conv2d.
+    exact=True (default): fp32 arithmetic as in the reference -- through the PyTorch-ROCm / MIOpen convolution ("library", the
+    default: 784 us for the head's five layers) or this library's exact-fp32 MFMA implicit GEMM (exact_impl="mfma" or env
+    UNINEXT_AMD_EXACT_CONV=mfma: a bitwise fmaf chain in k order, 1303 us -- kept as the bit-reproducible option, not the fast
+    one; profiles/r01_maskhead_bench.txt).  exact=False opts into the split-bf16 MFMA kernels of include/conv3x3_hip.h from
+    cached packed weights (361 us, ~2e-5 of the output scale, inside the 1e-4 parity bound).  Training, CPU, other dtypes or
+    geometries: PyTorch."""
     needs_grad = torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad)
+    if exact and (exact_impl or EXACT_CONV_IMPL) != "mfma":
+        return F.relu(conv(x))
     if (not needs_grad and tuple(conv.kernel_size) == (3, 3) and tuple(conv.padding) == (1, 1)
             and tuple(conv.stride) == (1, 1) and tuple(conv.dilation) == (1, 1) and conv.groups == 1
             and _ext.conv3x3_supported(x, conv.weight)):
@@ -143,9 +151,11 @@ class MaskHeadSmallConv(CachedModuleMixin, torch.nn.Module):
     `F.relu(self.layN(...))` steps go through conv3x3_relu.  `use_raft` is not covered (False in every shipped
     config, uninext/config.py:178)."""
 
-    # True (default): exact-fp32 MFMA kernel (the reference's arithmetic); False -- or env UNINEXT_AMD_SPLIT_BF16=1 -- opts into
-    # the split-bf16 path (3 of 4 partial products, ~2e-5 of the output scale; the fast one, see DESIGN.md)
+    # True (default): the reference's fp32 arithmetic (MIOpen convolutions, or this library's exact-fp32 MFMA kernel with
+    # exact_impl = "mfma"); False -- or env UNINEXT_AMD_SPLIT_BF16=1 -- opts into the split-bf16 MFMA kernels (3 of 4 partial
+    # products, ~2e-5 of the output scale; the fast ones, see DESIGN.md)
     exact_fp32 = os.environ.get("UNINEXT_AMD_SPLIT_BF16", "0") != "1"
+    exact_impl = None      # None: module-level EXACT_CONV_IMPL ("library"); "mfma": conv3x3_hip_f32
 
     def __init__(self, dim, fpn_dims, context_dim, use_raft=False, up_rate=4):
         super().__init__()
@@ -186,9 +196,9 @@ class MaskHeadSmallConv(CachedModuleMixin, torch.nn.Module):
 
     def forward(self, x, fpns):
         f = fpns if fpns is not None else (None, None, None)
-        e = self.exact_fp32
-        fused = conv3x3_relu(self._merge(x[-1], getattr(self, "adapter1", None), f[0], None), self.lay3, e)
-        fused = conv3x3_relu(self._merge(x[-2], getattr(self, "adapter2", None), f[1], fused), self.lay4, e)
-        fused_fpn = conv3x3_relu(self._merge(x[-3], getattr(self, "adapter3", None), f[2], fused), self.jia_dcn, e)
-        fused = conv3x3_relu(fused_fpn, self.lay1, e)
-        return conv3x3_relu(fused, self.lay2, e)
+        e, i = self.exact_fp32, self.exact_impl
+        fused = conv3x3_relu(self._merge(x[-1], getattr(self, "adapter1", None), f[0], None), self.lay3, e, i)
+        fused = conv3x3_relu(self._merge(x[-2], getattr(self, "adapter2", None), f[1], fused), self.lay4, e, i)
+        fused_fpn = conv3x3_relu(self._merge(x[-3], getattr(self, "adapter3", None), f[2], fused), self.jia_dcn, e, i)
+        fused = conv3x3_relu(fused_fpn, self.lay1, e, i)
+        return conv3x3_relu(fused, self.lay2, e, i)
