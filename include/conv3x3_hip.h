@@ -55,6 +55,20 @@ int conv3x3_hip_packed_f32(const float* in, const void* packed, const float* bia
                            int width, int cout, int relu, float* out, void* stream);
 
 /*
+ * The EXACT fp32 convolution in the same halo structure (round 4): weights re-ordered once by
+ * conv3x3_hip_pack_weight_exact_f32 into [cin / 16][9 taps][cout padded to 128][16] fp32 -- position 8 h + s of a chunk holds
+ * channel 2 s + h, the order in which v_mfma_f32_32x32x2_f32 consumes them (one float per lane and operand: lane (row, h) feeds
+ * channel 2 s + h in k-step s) -- conv3x3_hip_packed_exact_weight_bytes(cout, cin) bytes; conv3x3_hip_packed_exact_f32 stages
+ * the fp32 halo once per 16 input channels and runs 288 MFMAs per wave between two barriers.  Every output element is one
+ * chain of fp32 fused multiply-adds over (chunk, tap, k-step, h): exact fp32 arithmetic in a fixed order, bitwise repeatable,
+ * within fp32 round-off of precision 0 above and of any library convolution.  cin % 16 == 0.
+ */
+size_t conv3x3_hip_packed_exact_weight_bytes(int cout, int cin);   /* 0 if the geometry is unsupported */
+int conv3x3_hip_pack_weight_exact_f32(const float* weight, int cout, int cin, void* packed, void* stream);
+int conv3x3_hip_packed_exact_f32(const float* in, const void* packed, const float* bias, int batch, int cin, int height,
+                                 int width, int cout, int relu, float* out, void* stream);
+
+/*
  * out = skip + nearest-neighbour up-sampling of `low` to skip's size: the FPN-style merges of MaskHeadSmallConv.forward
  * (`x[-2] + F.interpolate(fused_x, size=..., mode="nearest")`, ddetrs_dn.py:1001,1012) in one pass instead of an
  * interpolate kernel, an add kernel and an intermediate.  skip / out [batch, channels, height, width], low

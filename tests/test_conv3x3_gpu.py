@@ -25,7 +25,7 @@ def dev():
     (3, 48, 9, 300, 130),      # wide rows, partial 128-channel tile
 ])
 @pytest.mark.parametrize("relu", [True, False])
-@pytest.mark.parametrize("precision", [0, 1, 2])     # 2: the packed-weight fast path of precision 1
+@pytest.mark.parametrize("precision", [0, 1, 2, 3])     # 2: the packed-weight fast path of precision 1; 3: the exact fp32 halo kernel
 def test_vs_oracle(B, C, H, W, E, relu, precision, dev):
     from oracle import conv3x3_oracle
     from uninext_amd import ext
@@ -38,11 +38,14 @@ def test_vs_oracle(B, C, H, W, E, relu, precision, dev):
     if precision == 2:
         packed = ext.conv3x3_pack_weight(t(w))
         run = lambda bias: ext.conv3x3_packed_forward(t(x), packed, E, bias, relu=relu).cpu().numpy()
+    elif precision == 3:
+        packed = ext.conv3x3_pack_weight(t(w), exact=True)
+        run = lambda bias: ext.conv3x3_packed_forward(t(x), packed, E, bias, relu=relu, exact=True).cpu().numpy()
     else:
         run = lambda bias: ext.conv3x3_forward(t(x), t(w), bias, relu=relu, precision=precision).cpu().numpy()
     out = run(t(b))
     assert max_abs(out, ref) < 1e-4 * max(1.0, float(np.abs(ref).max()))
-    if precision == 0:
+    if precision in (0, 3):
         assert max_abs(out, ref) < 5e-6 * max(1.0, float(np.abs(ref).max()))     # exact-fp32 products
     out = run(None)
     assert max_abs(out, conv3x3_oracle.conv3x3(x, w, None, relu)) < 1e-4 * max(1.0, float(np.abs(ref).max()))

@@ -50,6 +50,14 @@ def main():
             packed = ext.conv3x3_pack_weight(conv.weight.detach())
             t_split = timeit(lambda: ext.conv3x3_packed_forward(x, packed, cout, conv.bias, relu=True), args.reps)
             t_torch = timeit(lambda: torch.relu_(conv(x)), args.reps)
+            if cin % 16 == 0:      # round 4: the exact fp32 convolution in the halo structure
+                pe = ext.conv3x3_pack_weight(conv.weight.detach(), exact=True)
+                t_ex = timeit(lambda: ext.conv3x3_packed_forward(x, pe, cout, conv.bias, relu=True, exact=True), args.reps)
+                ref64_ = torch.relu(torch.nn.functional.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1))
+                e_ex = float((ext.conv3x3_packed_forward(x, pe, cout, conv.bias, relu=True, exact=True).double() - ref64_).abs().max()) / float(ref64_.abs().max())
+                print("%-8s exact fp32 HALO kernel (conv3x3_hip_packed_exact_f32) %7.1f us %5.1f TFLOP/s (%4.1f %% of 157.3) err %.0e"
+                      % (name, t_ex, flop / t_ex * 1e-6, 100 * flop / t_ex * 1e-6 / PEAK_TF, e_ex))
+                tot_e = globals().setdefault("_tot_e", [0.0]); tot_e[0] += t_ex
             ref = torch.relu(conv(x.double().cpu()).float() if False else conv(x))
             ref64 = torch.relu(torch.nn.functional.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1))
             sc = float(ref64.abs().max())
@@ -61,10 +69,16 @@ def main():
             print("%-8s %3d->%3d @ %3dx%3d %6.2f GFLOP | exact fp32 MFMA %7.1f us %5.1f TFLOP/s (%4.1f %% of 157.3) err %.0e | split-bf16 %7.1f us %6.1f TFLOP/s err %.0e | torch conv+relu %7.1f us err %.0e"
                   % (name, cin, cout, H, W, flop * 1e-9, t_hip, tf, 100 * tf / PEAK_TF, err0, t_split, flop / t_split * 1e-6, err1,
                      t_torch, errt))
-        print("five convolutions: exact %.1f us (%.1f TFLOP/s), split-bf16 %.1f us (%.1f TFLOP/s), torch %.1f us"
-              % (tot_h, tot_f / tot_h * 1e-6, tot_s, tot_f / tot_s * 1e-6, tot_t))
+        print("five convolutions: exact %.1f us (%.1f TFLOP/s), split-bf16 %.1f us (%.1f TFLOP/s), torch %.1f us; exact halo kernel %.1f us"
+              % (tot_h, tot_f / tot_h * 1e-6, tot_s, tot_f / tot_s * 1e-6, tot_t, globals().get("_tot_e", [0.0])[0]))
         head = MaskHeadSmallConv(256, None, 256).to(dev).eval()
         xs = [torch.randn(B, 256, h, w, device=dev) for h, w in ((100, 167), (50, 84), (25, 42))]
+        MaskHeadSmallConv.exact_fp32, MaskHeadSmallConv.exact_impl = True, "mfma"
+        t_exact_mod = timeit(lambda: head(xs, None), args.reps)
+        MaskHeadSmallConv.exact_fp32, MaskHeadSmallConv.exact_impl = True, None
+        t_lib_mod = timeit(lambda: head(xs, None), args.reps)
+        print("MaskHeadSmallConv.forward (bs 2), exact fp32: this library's halo kernels %.1f us, MIOpen route %.1f us" % (t_exact_mod, t_lib_mod))
+        MaskHeadSmallConv.exact_fp32, MaskHeadSmallConv.exact_impl = False, None
         t_mod = timeit(lambda: head(xs, None), args.reps)
         F = torch.nn.functional
 

@@ -18,14 +18,15 @@ def tensor_version(t):
     return -1 if t.is_inference() else t._version
 
 
-def packed_weight(module, pack_fn):
-    """Packed copy of module.weight produced by pack_fn(weight), cached on the module."""
+def packed_weight(module, pack_fn, slot="_msda_packed"):
+    """Packed copy of module.weight produced by pack_fn(weight), cached on the module.  `slot`: the cache entry -- two
+    packings of one weight (split-bf16 and exact fp32) keep one each ("_msda_packed", "_msda_packed_exact")."""
     w = module.weight
     key = (w.data_ptr(), tensor_version(w), str(w.device), tuple(w.shape))
-    cache = module.__dict__.get("_msda_packed")
+    cache = module.__dict__.get(slot)
     if cache is None or cache[0] != key:
         cache = (key, pack_fn(w.detach().contiguous()))
-        module.__dict__["_msda_packed"] = cache
+        module.__dict__[slot] = cache
     return cache[1]
 
 
@@ -54,6 +55,7 @@ def invalidate_packed(root):
     """Drop every packed-weight cache under `root` (an nn.Module); the next inference call re-packs."""
     for m in root.modules():
         m.__dict__.pop("_msda_packed", None)
+        m.__dict__.pop("_msda_packed_exact", None)
         m.__dict__.pop("_msda_packed_pair", None)
 
 

@@ -33,7 +33,8 @@ OTA_EXPORTS = ("ota_cost_hip_f32", "ota_dynamic_k_hip")                         
 OTA_MAX_BATCH = 64
 LSAP_MAX_BATCH = 32
 CONV3X3_EXPORTS = ("conv3x3_hip_f32", "conv3x3_hip_packed_weight_bytes", "conv3x3_hip_pack_weight_f32",
-                   "conv3x3_hip_packed_f32", "upsample_add_hip_f32")           # include/conv3x3_hip.h
+                   "conv3x3_hip_packed_f32", "conv3x3_hip_packed_exact_weight_bytes", "conv3x3_hip_pack_weight_exact_f32",
+                   "conv3x3_hip_packed_exact_f32", "upsample_add_hip_f32")     # include/conv3x3_hip.h
 
 _lib = None
 
@@ -109,6 +110,9 @@ def load():
     lib.conv3x3_hip_packed_weight_bytes.argtypes, lib.conv3x3_hip_packed_weight_bytes.restype = [i, i], ctypes.c_size_t
     lib.conv3x3_hip_pack_weight_f32.argtypes, lib.conv3x3_hip_pack_weight_f32.restype = [p, i, i, p, p], i
     lib.conv3x3_hip_packed_f32.argtypes, lib.conv3x3_hip_packed_f32.restype = [p, p, p, i, i, i, i, i, i, p, p], i
+    lib.conv3x3_hip_packed_exact_weight_bytes.argtypes, lib.conv3x3_hip_packed_exact_weight_bytes.restype = [i, i], ctypes.c_size_t
+    lib.conv3x3_hip_pack_weight_exact_f32.argtypes, lib.conv3x3_hip_pack_weight_exact_f32.restype = [p, i, i, p, p], i
+    lib.conv3x3_hip_packed_exact_f32.argtypes, lib.conv3x3_hip_packed_exact_f32.restype = [p, p, p, i, i, i, i, i, i, p, p], i
     lib.upsample_add_hip_f32.argtypes, lib.upsample_add_hip_f32.restype = [p, p, i, i, i, i, i, i, p, p], i
     lib.msda_hip_set_variant.argtypes, lib.msda_hip_set_variant.restype = [i, i], i
     lib.msda_hip_get_variant.argtypes, lib.msda_hip_get_variant.restype = [i], i

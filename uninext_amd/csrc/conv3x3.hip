@@ -454,6 +454,172 @@ conv3x3_packed(const float* __restrict__ in, const uint32_t* __restrict__ packed
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// conv3x3_exact<TJ, RELU, WM> (round 4): the EXACT fp32 convolution in the structure of conv3x3_packed.  The generic exact kernel
+// at the top of this file (one barrier per 16 k, nine-fold re-read of the input) reaches 38.8 % of the fp32 matrix pipe and loses
+// to MIOpen (646 vs 397 us on the 256 -> 256 layer at 100 x 167); the halo structure does not care about the operand width:
+//   * the 10 x 18 halo of an 8 x 16 pixel tile is staged ONCE per chunk of 16 input channels, as fp32 [halo pixel][16] (64 bytes
+//     per pixel, double buffered: 23 KB) and serves all nine taps with immediate LDS offsets -- one barrier per 288 MFMAs and wave;
+//   * v_mfma_f32_32x32x2_f32 takes ONE float per lane and operand: lane (r, h) holds channel 2 s + h of row r in k-step s.  Both
+//     operands are therefore stored with the chunk's channels in the order (h, s) -- position 8 h + s = channel 2 s + h -- so that
+//     the eight values a lane feeds into the eight k-steps of a tap are 32 contiguous bytes: two ds_read_b128 for the pixels, two
+//     16-byte global loads (two taps ahead, ring of three register sets) for the weights, which
+//     conv3x3_hip_pack_weight_exact_f32 re-orders once into [chunk][tap][cout][16];
+//   * every output element is ONE chain of fp32 fused multiply-adds over (chunk, tap, k-step, h): exact fp32 arithmetic in a fixed
+//     order (the f32 MFMA is an exact FMA), so the result is bitwise repeatable and within fp32 round-off of any other order.
+// TH: rows of the pixel tile (8 or 4; 16 columns): smaller tiles = more, shorter work units -- at these sizes the kernel runs at
+// the matrix pipe's rate and what is left to lose is the balance of units over the 1024 SIMDs (profiles/r04_conv3x3_exact.txt)
+template <int TH, int TJ, bool RELU, int WM>
+__global__ void __launch_bounds__(kThreads, 2)
+conv3x3_exact(const float* __restrict__ in, const float* __restrict__ packed, const float* __restrict__ bias, Geom g,
+              int tiles_x, int tiles_per_image, int cout_pad, float* __restrict__ out) {
+  constexpr int kHalo = (TH + 2) * kHaloW;                                   // halo pixels of the tile
+  __shared__ __attribute__((aligned(16))) float As[2][kHalo][kChunk];       // [buffer][halo pixel][(h, s)]
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int b = blockIdx.x / tiles_per_image, t_in = blockIdx.x - b * tiles_per_image;
+  const int ty0 = (t_in / tiles_x) * TH, tx0 = (t_in % tiles_x) * kTW;
+  const int n0 = blockIdx.y * (64 * TJ);
+  const int HW = g.H * g.W;
+
+  // ---- halo staging: items (halo pixel, h); this thread owns items tid and tid + 256: eight channels 2 s + h each ---------
+  const float* h_ptr[2];
+  bool h_ok[2], h_has[2];
+  int h_px[2], h_half[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int item = tid + r * kThreads;
+    h_has[r] = item < 2 * kHalo;
+    const int hp = item % kHalo;
+    h_px[r] = hp;
+    h_half[r] = (item / kHalo) & 1;
+    const int gy = ty0 - 1 + hp / kHaloW, gx = tx0 - 1 + hp % kHaloW;
+    h_ok[r] = h_has[r] && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
+    h_ptr[r] = in + ((int64_t)b * g.Cin + h_half[r]) * HW + (h_ok[r] ? gy * g.W + gx : 0);
+  }
+  float h_reg[2][8];
+  auto load_halo = [&](int chunk) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) h_reg[r][e] = h_ok[r] ? h_ptr[r][(int64_t)(chunk * kChunk + 2 * e) * HW] : 0.f;
+  };
+  auto store_halo = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+      if (h_has[r]) {
+        float* dst = &As[buf][h_px[r]][h_half[r] * 8];
+        *reinterpret_cast<f32x4*>(dst) = f32x4{h_reg[r][0], h_reg[r][1], h_reg[r][2], h_reg[r][3]};
+        *reinterpret_cast<f32x4*>(dst + 4) = f32x4{h_reg[r][4], h_reg[r][5], h_reg[r][6], h_reg[r][7]};
+      }
+  };
+
+  // ---- MFMA fragments (as conv3x3_packed: weights are the first operand, so accumulator rows are channels) ----------------
+  constexpr int WN = 4 / WM, TI = (TH / 2) / WM, WJ = 2 * TJ / WN;   // per wave: TI 32-pixel sub-tiles x WJ 32-channel tiles
+  static_assert(WJ >= 1 && TI >= 1, "wave layout");
+  const int wm = wv / WN, wn = wv % WN;
+  const int r32 = lane & 31, half = lane >> 5;
+  int a_off[TI];                                         // float offset of this lane's eight pixel values, sub-tile i, tap (0, 0)
+#pragma unroll
+  for (int i = 0; i < TI; ++i) a_off[i] = ((wm * 2 * TI + i * 2 + (r32 >> 4)) * kHaloW + (r32 & 15)) * kChunk + half * 8;
+  const int nb = n0 + wn * 32 * WJ + r32;
+  const float* w_lane = packed + (int64_t)nb * kChunk + half * 8;
+  const int64_t tap_stride = (int64_t)cout_pad * kChunk;
+  const int nchunks = g.Cin / kChunk, ntaps = nchunks * 9;
+  struct WFrag { f32x4 a[WJ], b[WJ]; };
+  auto load_w = [&](int ft, WFrag& f) {
+    const int fc = ft < ntaps ? ft : ntaps - 1;        // past the end: re-read the last tap (never used)
+    const float* p = w_lane + fc * tap_stride;
+#pragma unroll
+    for (int jn = 0; jn < WJ; ++jn) {
+      f.a[jn] = *reinterpret_cast<const f32x4*>(p + jn * 32 * kChunk);
+      f.b[jn] = *reinterpret_cast<const f32x4*>(p + jn * 32 * kChunk + 4);
+    }
+  };
+
+  f32x16 acc[TI][WJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int jn = 0; jn < WJ; ++jn)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][jn][v] = 0.f;
+
+  WFrag w0, w1, w2;
+  load_halo(0);
+  load_w(0, w0);
+  load_w(1, w1);
+  store_halo(0);
+  __syncthreads();
+
+  auto tap_mfma = [&](int buf, int tap, const WFrag& wf) {   // tap compile-time after unrolling
+    const int toff = ((tap / 3) * kHaloW + (tap % 3)) * kChunk;
+    // all sub-tiles' pixel values first, then k-step outermost: consecutive MFMAs go to DIFFERENT accumulators (a chain of
+    // MFMAs on one accumulator issues at its dependent latency and loses every slot another instruction takes in between)
+    f32x4 xa[TI], xb[TI];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+      xa[i] = *reinterpret_cast<const f32x4*>(&As[buf][0][0] + a_off[i] + toff);
+      xb[i] = *reinterpret_cast<const f32x4*>(&As[buf][0][0] + a_off[i] + toff + 4);
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int jn = 0; jn < WJ; ++jn)
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(s < 4 ? wf.a[jn][s & 3] : wf.b[jn][s & 3],
+                                                            s < 4 ? xa[i][s & 3] : xb[i][s & 3], acc[i][jn], 0, 0, 0);
+  };
+
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const int buf = chunk & 1, ft = chunk * 9;
+    if (chunk + 1 < nchunks) load_halo(chunk + 1);
+#pragma unroll
+    for (int t3 = 0; t3 < 3; ++t3) {                   // ring of three weight register sets, loads two taps ahead
+      load_w(ft + 3 * t3 + 2, w2);
+      tap_mfma(buf, 3 * t3, w0);
+      load_w(ft + 3 * t3 + 3, w0);
+      tap_mfma(buf, 3 * t3 + 1, w1);
+      load_w(ft + 3 * t3 + 4, w1);
+      tap_mfma(buf, 3 * t3 + 2, w2);
+    }
+    if (chunk + 1 < nchunks) store_halo(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: accumulator register v of lane l is (channel row 8 (v / 4) + 4 (l / 32) + v % 4, pixel l % 32) ------
+#pragma unroll
+  for (int i = 0; i < TI; ++i) {
+    const int gy = ty0 + wm * 2 * TI + i * 2 + (r32 >> 4), gx = tx0 + (r32 & 15);
+    const bool pix_ok = gy < g.H && gx < g.W;
+#pragma unroll
+    for (int jn = 0; jn < WJ; ++jn)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int n = n0 + wn * 32 * WJ + jn * 32 + 8 * (v / 4) + 4 * half + (v % 4);
+        if (pix_ok && n < g.Cout) {
+          float r = acc[i][jn][v] + (bias ? bias[n] : 0.f);
+          if (RELU) r = fmaxf(r, 0.f);
+          out[((int64_t)b * g.Cout + n) * HW + gy * g.W + gx] = r;
+        }
+      }
+  }
+}
+
+// weight [cout, cin, 3, 3] fp32 -> packed [cin / 16][9 taps][cout_pad][16] fp32, position 8 h + s of a chunk = channel 2 s + h
+__global__ void pack_weight_exact_kernel(const float* __restrict__ w, int cout, int cin, int cout_pad, float* __restrict__ packed) {
+  const int64_t total = (int64_t)(cin / kChunk) * 9 * cout_pad * kChunk;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int pos = (int)(idx % kChunk);
+    const int n = (int)((idx / kChunk) % cout_pad);
+    const int tap = (int)((idx / kChunk / cout_pad) % 9);
+    const int chunk = (int)(idx / kChunk / cout_pad / 9);
+    const int cl = 2 * (pos & 7) + (pos >> 3);
+    packed[idx] = n < cout ? w[((int64_t)n * cin + chunk * kChunk + cl) * 9 + tap] : 0.f;
+  }
+}
+
 // weight [cout, cin, 3, 3] fp32 -> packed [cin / 16][9 taps][hi, lo][cout_pad][16 channels] bf16
 __global__ void pack_weight_kernel(const float* __restrict__ w, int cout, int cin, int cout_pad, uint16_t* __restrict__ packed) {
   const int64_t total = (int64_t)(cin / kChunk) * 9 * cout_pad * kChunk;
@@ -590,6 +756,71 @@ int conv3x3_hip_packed_f32(const float* in, const void* packed, const float* bia
     if (relu) hipLaunchKernelGGL((conv3x3::conv3x3_packed<1, true, 2>), grid, dim3(conv3x3::kThreads), 0, st, in, pk, bias, g, tiles_x, tiles_x * tiles_y, cout_pad, out);
     else hipLaunchKernelGGL((conv3x3::conv3x3_packed<1, false, 2>), grid, dim3(conv3x3::kThreads), 0, st, in, pk, bias, g, tiles_x, tiles_x * tiles_y, cout_pad, out);
   }
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : dynmask_set_error((int)e, hipGetErrorString(e));
+}
+
+
+size_t conv3x3_hip_packed_exact_weight_bytes(int cout, int cin) {
+  if (cout <= 0 || cin <= 0 || cin % conv3x3::kChunk != 0) return 0;
+  return (size_t)(cin / conv3x3::kChunk) * 9 * conv3x3::cout_padded(cout) * conv3x3::kChunk * sizeof(float);
+}
+
+int conv3x3_hip_pack_weight_exact_f32(const float* weight, int cout, int cin, void* packed, void* stream) {
+  if (cout <= 0 || cin <= 0) return dynmask_set_error(CONV3X3_ERR_BAD_DIMS, "conv3x3: bad dimensions");
+  if (cin % conv3x3::kChunk != 0)
+    return dynmask_set_error(CONV3X3_ERR_UNSUPPORTED, "conv3x3: packed weights need cin to be a multiple of 16");
+  if (!weight || !packed) return dynmask_set_error(CONV3X3_ERR_NULL_POINTER, "conv3x3: null pointer argument");
+  hipLaunchKernelGGL(conv3x3::pack_weight_exact_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, weight, cout, cin,
+                     conv3x3::cout_padded(cout), static_cast<float*>(packed));
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : dynmask_set_error((int)e, hipGetErrorString(e));
+}
+
+int conv3x3_hip_packed_exact_f32(const float* in, const void* packed, const float* bias, int batch, int cin, int height,
+                                 int width, int cout, int relu, float* out, void* stream) {
+  if (batch < 0 || cin <= 0 || height <= 0 || width <= 0 || cout <= 0)
+    return dynmask_set_error(CONV3X3_ERR_BAD_DIMS, "conv3x3: bad dimensions");
+  if (cin % conv3x3::kChunk != 0)
+    return dynmask_set_error(CONV3X3_ERR_UNSUPPORTED, "conv3x3: packed weights need cin to be a multiple of 16");
+  const long long M = (long long)batch * height * width;
+  if (M == 0) return 0;
+  const int tiles_x = (width + conv3x3::kTW - 1) / conv3x3::kTW, tiles_y = (height + conv3x3::kTH - 1) / conv3x3::kTH;
+  const long long tiles = (long long)batch * tiles_x * tiles_y;
+  if (M >= (1ll << 31) || tiles >= (1ll << 31) || (long long)cin * height * width >= (1ll << 31))
+    return dynmask_set_error(CONV3X3_ERR_BAD_DIMS, "conv3x3: problem too large");
+  if (!in || !packed || !out) return dynmask_set_error(CONV3X3_ERR_NULL_POINTER, "conv3x3: null pointer argument");
+  conv3x3::Geom g;
+  g.B = batch; g.Cin = cin; g.H = height; g.W = width; g.Cout = cout; g.Mtot = (int)M; g.K = 9 * cin;
+  const int cout_pad = conv3x3::cout_padded(cout);
+  const float* pk = static_cast<const float*>(packed);
+  hipStream_t st = (hipStream_t)stream;
+  // Work units: the kernel runs at the matrix pipe's rate, so what decides the time is how evenly (tile, channel group) units
+  // spread over the SIMDs.  Largest unit (8 x 16 pixels x 128 channels: best weight-fragment reuse) when there are >= 4 per
+  // workgroup slot of the chip, then 8 x 16 x 64, else 4 x 16 x 64 -- CONV3X3_EXACT_UNIT=1|2|3 pins one (A/B).
+  static const int forced = std::getenv("CONV3X3_EXACT_UNIT") ? std::atoi(std::getenv("CONV3X3_EXACT_UNIT")) : 0;
+  int unit = 3;
+  if (cout > 64 && tiles * ((cout + 127) / 128) >= 2048) unit = 1;
+  else if (tiles * ((cout + 63) / 64) >= 2048) unit = 2;
+  if (forced >= 1 && forced <= 3) unit = forced;
+  if (unit == 1 && cout <= 64) unit = 2;
+#define CONV3X3_EXACT_LAUNCH(TH, TJ, WM, GX, GY, TX, TPI)                                                                             \
+  do {                                                                                                                                  \
+    dim3 grid((unsigned)(GX), (unsigned)(GY));                                                                                          \
+    if (relu) hipLaunchKernelGGL((conv3x3::conv3x3_exact<TH, TJ, true, WM>), grid, dim3(conv3x3::kThreads), 0, st, in, pk, bias, g, TX, TPI, cout_pad, out); \
+    else hipLaunchKernelGGL((conv3x3::conv3x3_exact<TH, TJ, false, WM>), grid, dim3(conv3x3::kThreads), 0, st, in, pk, bias, g, TX, TPI, cout_pad, out);     \
+  } while (0)
+  if (unit == 1) {
+    CONV3X3_EXACT_LAUNCH(8, 2, 1, tiles, (cout + 127) / 128, tiles_x, tiles_x * tiles_y);
+  } else if (unit == 2) {
+    CONV3X3_EXACT_LAUNCH(8, 1, 2, tiles, (cout + 63) / 64, tiles_x, tiles_x * tiles_y);
+  } else {
+    const int tiles_y4 = (height + 3) / 4;
+    const long long tiles4 = (long long)batch * tiles_x * tiles_y4;
+    if (tiles4 >= (1ll << 31)) return dynmask_set_error(CONV3X3_ERR_BAD_DIMS, "conv3x3: problem too large");
+    CONV3X3_EXACT_LAUNCH(4, 1, 2, tiles4, (cout + 63) / 64, tiles_x, tiles_x * tiles_y4);
+  }
+#undef CONV3X3_EXACT_LAUNCH
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : dynmask_set_error((int)e, hipGetErrorString(e));
 }

@@ -444,10 +444,26 @@ def conv3x3_forward(x, weight, bias=None, relu=False, precision=0):
     return out
 
 
-def conv3x3_pack_weight(weight):
+def conv3x3_pack_weight(weight, exact=False):
     """Split + re-order a [cout, cin, 3, 3] fp32 GPU weight once for conv3x3_packed_forward (cin % 16 == 0).
+    exact: the fp32 re-ordering of the exact kernel (conv3x3_hip_pack_weight_exact_f32) instead of the bf16 hi / lo split.
     Returns an opaque uint8 tensor on the same device."""
     lib = _lib.load()
+    if exact:
+        _check("weight", weight, weight.device)
+        if weight.dtype != torch.float32 or weight.dim() != 4 or tuple(weight.shape[2:]) != (3, 3):
+            raise RuntimeError("conv3x3_pack_weight: expected a float32 [cout, cin, 3, 3] weight")
+        cout, cin = weight.shape[:2]
+        nbytes = lib.conv3x3_hip_packed_exact_weight_bytes(cout, cin)
+        if nbytes == 0:
+            raise RuntimeError("conv3x3_pack_weight: cin must be a multiple of 16")
+        packed = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+        with torch.cuda.device(weight.device):
+            rc = lib.conv3x3_hip_pack_weight_exact_f32(weight.data_ptr(), cout, cin, packed.data_ptr(),
+                                                       ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            _raise(rc)
+        return packed
     _check("weight", weight, weight.device)
     if weight.dtype != torch.float32 or weight.dim() != 4 or tuple(weight.shape[2:]) != (3, 3):
         raise RuntimeError("conv3x3_pack_weight: expected a float32 [cout, cin, 3, 3] weight")
@@ -464,10 +480,13 @@ def conv3x3_pack_weight(weight):
     return packed
 
 
-def conv3x3_packed_forward(x, packed, cout, bias=None, relu=False):
+def conv3x3_packed_forward(x, packed, cout, bias=None, relu=False, exact=False):
     """3x3 / padding 1 convolution + bias (+ ReLU) from weights prepared by conv3x3_pack_weight: split-bf16 products
-    with fp32 accumulation (~2e-5 of the output scale), halo-tiled (include/conv3x3_hip.h)."""
+    with fp32 accumulation (~2e-5 of the output scale), or -- exact=True, weights packed with exact=True -- exact fp32 products
+    on v_mfma_f32_32x32x2_f32; both halo-tiled (include/conv3x3_hip.h)."""
     lib = _lib.load()
+    nbytes_fn = lib.conv3x3_hip_packed_exact_weight_bytes if exact else lib.conv3x3_hip_packed_weight_bytes
+    run = lib.conv3x3_hip_packed_exact_f32 if exact else lib.conv3x3_hip_packed_f32
     _check("x", x, x.device)
     _check("packed", packed, x.device)
     if bias is not None:
@@ -477,13 +496,13 @@ def conv3x3_packed_forward(x, packed, cout, bias=None, relu=False):
     if x.dtype != torch.float32 or x.dim() != 4:
         raise RuntimeError("conv3x3_packed_forward: expected a float32 x [B, C, H, W]")
     B, C, H, W = x.shape
-    if packed.dtype != torch.uint8 or packed.numel() != lib.conv3x3_hip_packed_weight_bytes(int(cout), C):
+    if packed.dtype != torch.uint8 or packed.numel() != nbytes_fn(int(cout), C):
         raise RuntimeError("conv3x3_packed_forward: `packed` does not belong to a [%d, %d, 3, 3] weight" % (cout, C))
     out = torch.empty((B, int(cout), H, W), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        rc = lib.conv3x3_hip_packed_f32(x.data_ptr(), packed.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                        B, C, H, W, int(cout), int(bool(relu)), out.data_ptr(),
-                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        rc = run(x.data_ptr(), packed.data_ptr(), bias.data_ptr() if bias is not None else None,
+                 B, C, H, W, int(cout), int(bool(relu)), out.data_ptr(),
+                 ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     if rc != 0:
         _raise(rc)
     return out

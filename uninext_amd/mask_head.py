@@ -122,6 +122,15 @@ def _packed_weight(conv):
     return packed_weight(conv, _ext.conv3x3_pack_weight)
 
 
+def _pack_exact(weight):
+    return _ext.conv3x3_pack_weight(weight, exact=True)
+
+
+def _packed_weight_exact(conv):
+    """fp32 re-ordered copy of conv.weight for the exact halo kernel, cached like the split-bf16 one (its own cache slot)."""
+    return packed_weight(conv, _pack_exact, slot="_msda_packed_exact")
+
+
 EXACT_CONV_IMPL = os.environ.get("UNINEXT_AMD_EXACT_CONV", "library")   # "library" | "mfma"
 
 
@@ -141,6 +150,9 @@ def conv3x3_relu(x, conv, exact=True, exact_impl=None):
             and _ext.conv3x3_supported(x, conv.weight)):
         if not exact and conv.weight.shape[1] % 16 == 0:
             return _ext.conv3x3_packed_forward(x.contiguous(), _packed_weight(conv), conv.weight.shape[0], conv.bias, relu=True)
+        if exact and conv.weight.shape[1] % 16 == 0 and conv.weight.shape[0] >= 32:
+            return _ext.conv3x3_packed_forward(x.contiguous(), _packed_weight_exact(conv), conv.weight.shape[0], conv.bias,
+                                               relu=True, exact=True)
         return _ext.conv3x3_forward(x.contiguous(), conv.weight.contiguous(), conv.bias, relu=True)
     return F.relu(conv(x))
 
