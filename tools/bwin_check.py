@@ -25,6 +25,7 @@ def run(x, go, variant):
 
 
 def main():
+    kernel = sys.argv[1] if len(sys.argv) > 1 else "msda_bwd_win"
     _lib.load()
     cases = [(fl, workloads.R50_LEVELS_INFER, 8, 2) for fl in ("model", "uniform", "wide")]
     cases += [(fl, lv, 8, 2) for lv in ODD for fl in ("model", "wide")]
@@ -40,13 +41,13 @@ def main():
         x["loc"][0, 5, heads - 1, 3, 3, 1] = float("inf")
         go = torch.randn(batch, S, heads * 32, generator=torch.Generator().manual_seed(9)).cuda()
         rv, rl, ra = run(x, go, "msda_bwd_generic")
-        gv, gl, ga = run(x, go, "msda_bwd_win")
+        gv, gl, ga = run(x, go, kernel)
         kern = _lib.last_kernel("backward")
         e_v = float((gv - rv).abs().max()); e_a = float((ga - ra).abs().max())
         dl = (gl - rl).abs()
         e_l = [float(dl[:, :, :, l].max()) / (1e-4 * max(lv[l])) for l in range(4)]
         fin = bool(torch.isfinite(gv).all() and torch.isfinite(gl).all() and torch.isfinite(ga).all())
-        ok = kern == "msda_bwd_win" and e_v < 1e-4 and e_a < 5e-4 and max(e_l) < 1.0 and fin
+        ok = kern == kernel and e_v < 1e-4 and e_a < 5e-4 and max(e_l) < 1.0 and fin
         print("%-8s M=%-2d N=%d %-48s %-13s grad_value %.2e (max %.1f) grad_attn %.2e grad_loc/bound %s %s%s" % (
             fl, heads, batch, str(lv), kern, e_v, float(rv.abs().max()), e_a, ["%.2f" % e for e in e_l], "" if fin else "NON-FINITE ",
             "" if ok else "  <-- MISMATCH"), flush=True)

@@ -417,6 +417,14 @@ int launch_backward<float>(int variant, const float* grad_out, const float* valu
     return launch_backward_regions(grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, stream);
   }
   if (variant == kBwdRegions) variant = tl ? kTiled : kGeneric;
+  constexpr int kBwdWin2 = 7;           // backward variant 7: msda_bwd_win2 (one window set, two workgroups per CU; experiments/)
+#ifdef MSDA_EXPERIMENTS
+  if (variant == kBwdWin2 && win2_backward_ok(d)) {
+    *kernel_name = "msda_bwd_win2";
+    return launch_backward_win2(grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, stream);
+  }
+#endif
+  if (variant == kBwdWin2) variant = kBwdWin;
   if (variant == kBwdWin && win_backward_ok(d)) {
     *kernel_name = "msda_bwd_win";
     return launch_backward_win(grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, stream);

@@ -140,6 +140,11 @@ int launch_backward_win(const float* grad_out, const float* value, const int64_t
 // msda_fwd_win.hip: encoder forward with LDS windows on all four levels (fp32, D = 32, L = P = 4, Lq == S).
 bool win_forward_ok(const Dims& d);
 bool win_forward_auto(const Dims& d, hipStream_t stream);   // auto dispatch: take the window kernel for this call? (consumes the call context)
+// experiments/msda_bwd_win2.hip (`make experiments`): the same partition with ONE window set per workgroup (value windows, then accumulators): two workgroups per CU
+bool win2_backward_ok(const Dims& d);
+int launch_backward_win2(const float* grad_out, const float* value, const int64_t* shapes, const int64_t* lsi,
+                         const float* loc, const float* attn, const Dims& d, float* grad_value, float* grad_loc,
+                         float* grad_attn, hipStream_t stream);
 int backward_site_choice(const Dims& d);                     // backward of an encoder-shaped call: 1 = msda_bwd_win (the site's forward calls reported near samples), 2 = msda_bwd_regions (they reported far ones), 0 = no report to go by (consumes the context)
 void set_call_context(int slot, unsigned flags);            // include/msda_hip.h: msda_hip_set_call_context
 void drop_call_context();
