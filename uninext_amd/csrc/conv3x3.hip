@@ -474,7 +474,13 @@ __global__ void __launch_bounds__(kThreads, 2)
 conv3x3_exact(const float* __restrict__ in, const float* __restrict__ packed, const float* __restrict__ bias, Geom g,
               int tiles_x, int tiles_per_image, int cout_pad, float* __restrict__ out) {
   constexpr int kHalo = (TH + 2) * kHaloW;                                   // halo pixels of the tile
-  __shared__ __attribute__((aligned(16))) float As[2][kHalo][kChunk];       // [buffer][halo pixel][(h, s)]
+  // pixel pitch 80 bytes, not 64: a ds_read_b128 is served 16 lanes at a time = 16 consecutive halo pixels, and 16 x 64 B covers
+  // only a quarter of the banks (4-way conflicts: 74 % of the LDS-active cycles, profiles/r04_conv3x3_exact.txt); 5 x 16 B is odd
+#ifndef CONV3X3_EXACT_PITCH
+#define CONV3X3_EXACT_PITCH 20
+#endif
+  constexpr int kPitch = CONV3X3_EXACT_PITCH;                               // floats per halo pixel in the LDS
+  __shared__ __attribute__((aligned(16))) float As[2][kHalo][kPitch];       // [buffer][halo pixel][(h, s)]
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int b = blockIdx.x / tiles_per_image, t_in = blockIdx.x - b * tiles_per_image;
@@ -521,7 +527,7 @@ conv3x3_exact(const float* __restrict__ in, const float* __restrict__ packed, co
   const int r32 = lane & 31, half = lane >> 5;
   int a_off[TI];                                         // float offset of this lane's eight pixel values, sub-tile i, tap (0, 0)
 #pragma unroll
-  for (int i = 0; i < TI; ++i) a_off[i] = ((wm * 2 * TI + i * 2 + (r32 >> 4)) * kHaloW + (r32 & 15)) * kChunk + half * 8;
+  for (int i = 0; i < TI; ++i) a_off[i] = ((wm * 2 * TI + i * 2 + (r32 >> 4)) * kHaloW + (r32 & 15)) * kPitch + half * 8;
   const int nb = n0 + wn * 32 * WJ + r32;
   const float* w_lane = packed + (int64_t)nb * kChunk + half * 8;
   const int64_t tap_stride = (int64_t)cout_pad * kChunk;
@@ -545,23 +551,24 @@ conv3x3_exact(const float* __restrict__ in, const float* __restrict__ packed, co
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[i][jn][v] = 0.f;
 
-  WFrag w0, w1, w2;
-  load_halo(0);
-  load_w(0, w0);
-  load_w(1, w1);
-  store_halo(0);
-  __syncthreads();
-
-  auto tap_mfma = [&](int buf, int tap, const WFrag& wf) {   // tap compile-time after unrolling
-    const int toff = ((tap / 3) * kHaloW + (tap % 3)) * kChunk;
-    // all sub-tiles' pixel values first, then k-step outermost: consecutive MFMAs go to DIFFERENT accumulators (a chain of
-    // MFMAs on one accumulator issues at its dependent latency and loses every slot another instruction takes in between)
-    f32x4 xa[TI], xb[TI];
+  // Everything an MFMA waits for is requested a long way ahead: the NINE taps' weights of chunk c + 1 while chunk c is multiplied
+  // (72 registers; two taps ahead -- ~2000 clocks -- was inside the L2's latency under load), the halo of chunk c + 1 likewise, and
+  // the pixel fragments of tap t + 1 before the MFMAs of tap t (CONV3X3_EXACT_AHEAD=0: the round-4 first version, for A/B).
+#ifndef CONV3X3_EXACT_AHEAD
+#define CONV3X3_EXACT_AHEAD 1
+#endif
+  struct XFrag { f32x4 a[TI], b[TI]; };
+  auto load_x = [&](int buf, int tap, XFrag& x) {        // tap compile-time after unrolling
+    const int toff = ((tap / 3) * kHaloW + (tap % 3)) * kPitch;
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
-      xa[i] = *reinterpret_cast<const f32x4*>(&As[buf][0][0] + a_off[i] + toff);
-      xb[i] = *reinterpret_cast<const f32x4*>(&As[buf][0][0] + a_off[i] + toff + 4);
+      x.a[i] = *reinterpret_cast<const f32x4*>(&As[buf][0][0] + a_off[i] + toff);
+      x.b[i] = *reinterpret_cast<const f32x4*>(&As[buf][0][0] + a_off[i] + toff + 4);
     }
+  };
+  // k-step outermost: consecutive MFMAs go to DIFFERENT accumulators (a chain of MFMAs on one accumulator issues at its
+  // dependent latency and loses every slot another instruction takes in between)
+  auto tap_mfma = [&](const XFrag& x, const WFrag& wf) {
 #pragma unroll
     for (int s = 0; s < 8; ++s)
 #pragma unroll
@@ -569,24 +576,61 @@ conv3x3_exact(const float* __restrict__ in, const float* __restrict__ packed, co
 #pragma unroll
         for (int jn = 0; jn < WJ; ++jn)
           acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(s < 4 ? wf.a[jn][s & 3] : wf.b[jn][s & 3],
-                                                            s < 4 ? xa[i][s & 3] : xb[i][s & 3], acc[i][jn], 0, 0, 0);
+                                                            s < 4 ? x.a[i][s & 3] : x.b[i][s & 3], acc[i][jn], 0, 0, 0);
   };
-
+#if CONV3X3_EXACT_AHEAD
+  WFrag wc[9], wnx[9];
+  load_halo(0);
+#pragma unroll
+  for (int t = 0; t < 9; ++t) load_w(t, wc[t]);
+  store_halo(0);
+  __syncthreads();
+  XFrag x0, x1;
+  load_x(0, 0, x0);
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const int buf = chunk & 1, ft = (chunk + 1) * 9;
+    if (chunk + 1 < nchunks) load_halo(chunk + 1);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) load_w(ft + t, wnx[t]);  // (past the end: re-reads the last tap, never used)
+#pragma unroll
+    for (int t = 0; t < 9; t += 2) {
+      if (t + 1 < 9) load_x(buf, t + 1, x1);
+      tap_mfma(x0, wc[t]);
+      if (t + 1 < 9) {
+        if (t + 2 < 9) load_x(buf, t + 2, x0);
+        tap_mfma(x1, wc[t + 1]);
+      }
+    }
+    if (chunk + 1 < nchunks) store_halo(buf ^ 1);
+    __syncthreads();
+    load_x(buf ^ 1, 0, x0);                            // (after the last chunk: stale data, never used)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wc[t] = wnx[t];
+  }
+#else
+  WFrag w0, w1, w2;
+  load_halo(0);
+  load_w(0, w0);
+  load_w(1, w1);
+  store_halo(0);
+  __syncthreads();
+  XFrag xs;
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     const int buf = chunk & 1, ft = chunk * 9;
     if (chunk + 1 < nchunks) load_halo(chunk + 1);
 #pragma unroll
     for (int t3 = 0; t3 < 3; ++t3) {                   // ring of three weight register sets, loads two taps ahead
       load_w(ft + 3 * t3 + 2, w2);
-      tap_mfma(buf, 3 * t3, w0);
+      load_x(buf, 3 * t3, xs); tap_mfma(xs, w0);
       load_w(ft + 3 * t3 + 3, w0);
-      tap_mfma(buf, 3 * t3 + 1, w1);
+      load_x(buf, 3 * t3 + 1, xs); tap_mfma(xs, w1);
       load_w(ft + 3 * t3 + 4, w1);
-      tap_mfma(buf, 3 * t3 + 2, w2);
+      load_x(buf, 3 * t3 + 2, xs); tap_mfma(xs, w2);
     }
     if (chunk + 1 < nchunks) store_halo(buf ^ 1);
     __syncthreads();
   }
+#endif
 
   // ---- epilogue: accumulator register v of lane l is (channel row 8 (v / 4) + 4 (l / 32) + v % 4, pixel l % 32) ------
 #pragma unroll
