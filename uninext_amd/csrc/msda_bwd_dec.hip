@@ -121,6 +121,8 @@ msda_bwd_dec(const float* __restrict__ grad_out, const float* __restrict__ value
     const bool live = q < q1;
     if (!__ballot(live)) break;
     const int64_t pair = ((int64_t)b * d.Lq + (live ? q : q0)) * M + m;
+    float* const ga_p = grad_attn + pair * 16;              // this pair's 16 + 32 outputs
+    float* const gl_p = grad_loc + pair * 32;
     const float locv = locv_n, attv = attv_n;
     const float g = MSDA_BWD_DEC_AHEAD ? g_n : (live ? grad_out[pair * 32 + lane] : 0.f);
     if (MSDA_BWD_DEC_AHEAD) fetch_pair(q + kDT / 32);
@@ -172,7 +174,6 @@ msda_bwd_dec(const float* __restrict__ grad_out, const float* __restrict__ value
       const int slot0 = l == 3 ? 0 : base2;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int64_t si = pair * 16 + l * 4 + k;
         float pa = 0.f, pw = 0.f, ph = 0.f;
         if (__ballot(L.in[k])) {                             // wave-uniform (the sums need every lane of the half)
           if (L.in[k]) {
@@ -200,9 +201,9 @@ msda_bwd_dec(const float* __restrict__ grad_out, const float* __restrict__ value
           ph = half_sum(ph);
         }
         if (live && lane == 0) {
-          grad_attn[si] = pa;
-          grad_loc[si * 2] = (float)Wl * pw;
-          grad_loc[si * 2 + 1] = (float)Hl * ph;
+          ga_p[l * 4 + k] = pa;
+          gl_p[2 * (l * 4 + k)] = (float)Wl * pw;
+          gl_p[2 * (l * 4 + k) + 1] = (float)Hl * ph;
         }
       }
     };
