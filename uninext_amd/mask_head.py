@@ -137,11 +137,13 @@ EXACT_CONV_IMPL = os.environ.get("UNINEXT_AMD_EXACT_CONV", "library")   # "libra
 def conv3x3_relu(x, conv, exact=True, exact_impl=None):
     """`F.relu(conv(x))` for a 3x3 / padding 1 nn.Conv2d.
     exact=True (default): fp32 arithmetic as in the reference -- through the PyTorch-ROCm / MIOpen convolution ("library", the
-    default: 784 us for the head's five layers) or this library's exact-fp32 MFMA implicit GEMM (exact_impl="mfma" or env
-    UNINEXT_AMD_EXACT_CONV=mfma: a bitwise fmaf chain in k order, 1303 us -- kept as the bit-reproducible option, not the fast
-    one; profiles/r01_maskhead_bench.txt).  exact=False opts into the split-bf16 MFMA kernels of include/conv3x3_hip.h from
-    cached packed weights (361 us, ~2e-5 of the output scale, inside the 1e-4 parity bound).  Training, CPU, other dtypes or
-    geometries: PyTorch."""
+    default: ~750 us for the head's module forward at bs 2) or this library's exact-fp32 MFMA kernels (exact_impl="mfma" or env
+    UNINEXT_AMD_EXACT_CONV=mfma): conv3x3_hip_packed_exact_f32 -- halo tiles, one fixed-order fp32 FMA chain per output, bitwise
+    repeatable; ~930 us for the module, faster than MIOpen on the 256 -> 256 layer at 50 x 84 and behind it elsewhere
+    (profiles/r04_conv3x3_exact.txt) -- or conv3x3_hip_f32 for layers it does not take (input channels not a multiple of 16,
+    fewer than 32 outputs).  exact=False opts into the split-bf16 MFMA kernels of include/conv3x3_hip.h from cached packed
+    weights (~390 us, ~2e-5 of the output scale, inside the 1e-4 parity bound).  Training, CPU, other dtypes or geometries:
+    PyTorch."""
     needs_grad = torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad)
     if exact and (exact_impl or EXACT_CONV_IMPL) != "mfma":
         return F.relu(conv(x))
@@ -167,7 +169,7 @@ class MaskHeadSmallConv(CachedModuleMixin, torch.nn.Module):
     # exact_impl = "mfma"); False -- or env UNINEXT_AMD_SPLIT_BF16=1 -- opts into the split-bf16 MFMA kernels (3 of 4 partial
     # products, ~2e-5 of the output scale; the fast ones)
     exact_fp32 = os.environ.get("UNINEXT_AMD_SPLIT_BF16", "0") != "1"
-    exact_impl = None      # None: module-level EXACT_CONV_IMPL ("library"); "mfma": conv3x3_hip_f32
+    exact_impl = None      # None: module-level EXACT_CONV_IMPL ("library"); "mfma": conv3x3_hip_packed_exact_f32 / conv3x3_hip_f32
 
     def __init__(self, dim, fpn_dims, context_dim, use_raft=False, up_rate=4):
         super().__init__()
