@@ -23,7 +23,10 @@ namespace {
 #define MSDA_BWD_DEC_THREADS 1024
 #endif
 constexpr int kDT = MSDA_BWD_DEC_THREADS;                                  // threads per workgroup = 32 half-waves = 32 pairs in flight
-constexpr int kAccSlots = 1200;                            // accumulator slots (pixels) of 32 int32: 150 KB
+#ifndef MSDA_BWD_DEC_SLOTS
+#define MSDA_BWD_DEC_SLOTS 1200
+#endif
+constexpr int kAccSlots = MSDA_BWD_DEC_SLOTS;              // accumulator slots (pixels) of 32 int32: 150 KB
 struct DMeta { unsigned gmax_bits, amax_bits; };
 constexpr int kDecLds = kAccSlots * 128 + 16;
 
@@ -249,7 +252,7 @@ static int dec_slices(const Dims& d) {
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   const int64_t heads = std::max<int64_t>(1, (int64_t)d.M * d.N);
   int nsl = env > 0 ? env : (int)std::min<int64_t>(16, (cus + heads - 1) / heads);
-  nsl = std::max(1, std::min(nsl, 16));
+  nsl = std::max(1, std::min(nsl, env > 0 ? kDecMaxSlices : 16));
   nsl = std::min(nsl, (d.Lq + 31) / 32);
   return std::max(nsl, (d.Lq + kDecSliceQueries - 1) / kDecSliceQueries);
 }
