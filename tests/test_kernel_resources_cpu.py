@@ -24,6 +24,7 @@ LIMITS = {
     "msda_bwd_win.hip": {"msda::msda_bwd_win": (168, 0)},
     "msda_bwd_tiled.hip": {"msda::msda_bwd_tiled": (168, 0)},
     "msda_bwd.hip": {"msda::msda_bwd_generic<float, 1>": (96, 0)},
+    "msda_bwd_q.hip": {"msda::msda_bwd_q": (64, 0)},
     # round 4: the lane-parallel prefetch of a pair's inputs keeps 9 values in scratch across the query loop's head; measured WITH
     # them: 80 us against 88 for the version without (profiles/r04_backward_decoder.txt)
     "msda_bwd_dec.hip": {"msda::msda_bwd_dec": (128, 36)},

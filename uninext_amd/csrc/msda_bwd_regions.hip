@@ -393,7 +393,13 @@ int launch_backward_regions(const float* grad_out, const float* value, const int
   // counts of this call's bins start at zero whatever an earlier (possibly aborted) call left: 1.4 MB, ~2 us
   if (hipError_t e = hipMemsetAsync(counts, 0, b_counts, stream); e != hipSuccess) return (int)e;
 
-  if (int rc = launch_backward_tiled_nogv(grad_out, value, shapes, lsi, loc, attn, d, grad_loc, grad_attn, stream)) return rc;
+  // the query side: msda_bwd_q (round 4; MSDA_BWD_REGIONS_Q=0: msda_bwd_tiled with its grad_value half compiled out, A/B)
+  static const bool q_pass = !(std::getenv("MSDA_BWD_REGIONS_Q") && std::getenv("MSDA_BWD_REGIONS_Q")[0] == '0');
+  if (q_pass && q_backward_ok(d)) {
+    if (int rc = launch_backward_q(grad_out, value, shapes, lsi, loc, attn, d, grad_loc, grad_attn, stream)) return rc;
+  } else if (int rc = launch_backward_tiled_nogv(grad_out, value, shapes, lsi, loc, attn, d, grad_loc, grad_attn, stream)) {
+    return rc;
+  }
   const dim3 fgrid((unsigned)((d.Lq + kRT - 1) / kRT), (unsigned)d.M, (unsigned)d.N);
   hipLaunchKernelGGL(msda_bwd_regions_file<false>, fgrid, dim3(kRT), 0, stream, shapes, loc, attn, d, hist_cap, counts,
                      static_cast<const uint32_t*>(starts), cursors, recs);

@@ -121,6 +121,10 @@ int launch_backward_tiled_nogv(const float* grad_out, const float* value, const 
 // msda_bwd_regions.hip: encoder backward with grad_value summed on the DESTINATION side (fp32, D = 32, L = P = 4, Lq == S):
 // no global atomics, time independent of where the samples fall
 bool regions_backward_ok(const Dims& d);
+// msda_bwd_q.hip: grad_sampling_loc / grad_attn_weight alone, in msda_fwd_lg3's gather structure (the query-side pass of msda_bwd_regions)
+bool q_backward_ok(const Dims& d);
+int launch_backward_q(const float* grad_out, const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc,
+                      const float* attn, const Dims& d, float* grad_loc, float* grad_attn, hipStream_t stream);
 size_t regions_workspace_bytes(const Dims& d);              // include/msda_hip.h: msda_hip_backward_workspace_bytes
 void set_call_workspace(void* p, size_t bytes);              // lent to the next backward call of this thread (nullptr: none)
 int launch_backward_regions(const float* grad_out, const float* value, const int64_t* shapes, const int64_t* lsi,
