@@ -56,7 +56,9 @@ def main():
                     "instead of --kinds at the R50 inference shapes")
     args = ap.parse_args()
     _lib.load()
-    vf = [int(v) for v in args.variants_fwd.split(",") if v] or list(range(1, len(_lib.variants("forward"))))
+    # default: every forward kernel THIS library carries (the default build names the experiments "exp:..." and refuses them)
+    vf = [int(v) for v in args.variants_fwd.split(",") if v] or [
+        k for k, n in enumerate(_lib.variants("forward")) if k >= 1 and not n.startswith("exp:")]
     vb = [int(v) for v in args.variants_bwd.split(",") if v] or [1, 2, 3]
     names = list(workloads.WORKLOADS) if args.workloads == "all" else [w for w in args.workloads.split(",") if w]
     for kind in (names or args.kinds.split(",")):
