@@ -80,7 +80,7 @@ def parse_args():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the flavours / backward / train_step / ddp measurements (profiling passes)")
     ap.add_argument("--extras-only", default="",
-                    help="comma list of extras to run (flavours,backward,train,ddp,slice); default all")
+                    help="comma list of extras to run (flavours,backward,train,ddp,slice,matcher); default all")
     return ap.parse_args()
 
 
@@ -439,6 +439,28 @@ def measure_ddp(enc, dec, world, reps=5):
             "op_fwd_bwd_ms": st, "overlapped_ms": ov, "backend": "nccl (RCCL over xGMI)"}
 
 
+def measure_matcher(reps=20):
+    """simOTA assignment (dd/matcher.py:286-447, the matcher of every decoder layer under MODEL.OTA) at config 5's shapes: bs 2,
+    900 queries, 256 tokens, 7 + 19 targets -- the two HIP kernels of include/ota_hip.h with their one host copy per call beside
+    the PyTorch composition of the same data flow (batched top-k; the reference's per-target loop is slower still).  Integer
+    results: the indices must be equal."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import ota_bench
+    from uninext_amd.matcher import HungarianMatcherVL
+    dev = torch.device("cuda:%d" % torch.cuda.current_device())
+    outputs, targets = ota_bench.make(2, 900, 256, [7, 19], 1, dev)
+    m = HungarianMatcherVL(cost_class=2, cost_bbox=5, cost_giou=2)
+    m.device_ota = True
+    dev_idx, _ = m.forward_ota(outputs, targets)
+    t_dev = ota_bench.wall(lambda: m.forward_ota(outputs, targets), reps)
+    m.device_ota = False
+    cmp_idx, _ = m.forward_ota(outputs, targets)
+    t_cmp = ota_bench.wall(lambda: m.forward_ota(outputs, targets), max(reps // 4, 3))
+    same = all(torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]) for x, y in zip(dev_idx, cmp_idx))
+    return {"simota_device_us_per_call": t_dev, "simota_pytorch_composition_us_per_call": t_cmp, "same_indices": bool(same),
+            "workload": "HungarianMatcherVL.forward_ota, bs 2, Q 900, T 256, targets per image [7, 19]; wall clock incl. the host copy of the counts"}
+
+
 def measure_model_slice(reps=6):
     """SURVEY.md 8(d) "model-level accounting": the GPU-resident callers of the path that this repository has built, strung
     together the way one bs = 2 inference step of the R50 det + seg model runs them -- six encoder layers (self-attention =
@@ -599,7 +621,7 @@ def main():
     elapsed = max_over_ranks(time.perf_counter() - t0, world)
 
     extras = {}
-    want = set(args.extras_only.split(",")) if args.extras_only else {"flavours", "backward", "train", "ddp", "slice"}
+    want = set(args.extras_only.split(",")) if args.extras_only else {"flavours", "backward", "train", "ddp", "slice", "matcher"}
     if not args.no_extras:   # every rank takes part (collectives inside), rank 0 reports
         def extra(key, fn):      # an extra that fails must not take the contract line with it
             try:
@@ -627,6 +649,8 @@ def main():
             extra("ddp", lambda: measure_ddp(tenc6, tdec6, world))
         if "slice" in want and rank == 0:
             extra("model_slice", measure_model_slice)
+        if "matcher" in want and rank == 0:
+            extra("matcher", measure_matcher)
 
     if rank == 0:
         sampled = events[::EVENT_EVERY]
