@@ -277,7 +277,7 @@ const char* msda_hip_last_kernel(int which);
  * a counter of its own and its last workgroup stores (count, sequence number) in host-mapped memory.  The report of a
  * launch is consumed at the call site's SECOND call after it, behind a wait on an event recorded after that launch
  * (normally complete long before), so the kernel a call takes depends on the call sequence only, never on timing: window
- * kernel (every 8th launch reporting once the first reports are in) until a report says far fraction > 0.20, then the
+ * kernel (every 8th launch reporting once the first reports are in) until a report says far fraction > 0.33, then the
  * gather kernel with every 64th call sent through the window kernel to refresh the report.  Two runs of the same call sequence are bitwise equal; the two kernels differ from each
  * other in fp32 summation order only.  Under a stream capture (events cannot be waited for) and with
  * MSDA_HIP_FWD_ADAPTIVE=0 in the environment variant 0 takes the gather kernel.
@@ -285,7 +285,7 @@ const char* msda_hip_last_kernel(int which);
  * Backward (variant 0, fp32, encoder shape): msda_bwd_win -- value and gradient windows in LDS -- when the call carries a
  * context (geometry vouched for, not deterministic) and the FORWARD calls of that call site have last reported a far
  * fraction <= 0.05; msda_bwd_regions -- grad_value summed on the destination side, no global atomics, time independent of
- * the locations -- when they have last reported one >= 0.30; msda_bwd_tiled otherwise (no context, no forward yet, in
+ * the locations -- when they have last reported one > 0.33; msda_bwd_tiled otherwise (no context, no forward yet, in
  * between).  A backward call launches no report and waits for nothing: its choice follows the call sequence of the site's
  * forward calls.  msda_bwd_regions keeps a per-device workspace (bin tables + up to four 32-byte records per sample, ~0.7 GB
  * at the R50 training shapes, allocated at its first call, handed from stream to stream behind an event; inside a stream

@@ -120,7 +120,7 @@ def _auto(MSDA, lib, x, site):
 
 def test_automatic_forward_choice_follows_the_reported_locality(dev, api):
     """include/msda_hip.h: a reporting window-kernel launch counts the samples that missed its windows; a call site takes
-    the window kernel until a report says far fraction > 0.20 and the gather kernel afterwards, re-probing every 64th call.
+    the window kernel until a report says far fraction > 0.33 and the gather kernel afterwards, re-probing every 64th call.
     Reports are consumed at the site's second call after the launch: the kernel sequence is a function of the call
     sequence.  The choice never changes a result beyond summation order."""
     from uninext_amd import workloads

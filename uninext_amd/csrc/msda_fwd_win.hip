@@ -58,10 +58,12 @@ namespace {
 #define MSDA_WIN_FASTDMA 1
 #endif
 constexpr int kT = 512, kWaves = kT / 64, kQuads = kT / 4;
-// auto dispatch (win_forward_auto): the window kernel is used while the last reported far fraction is at most this
-// (bench flavours: far 0.02 -> 78 us against 107 for msda_fwd_lg3, 0.41 -> 147 against 101-123, 0.93 -> 184 against
-// 106-121: the lines cross near 0.2), and the statistic is refreshed every kReprobe-th call otherwise
-constexpr double kFarFractionMax = 0.20;
+// auto dispatch (win_forward_auto): the window kernel is used while the last reported far fraction is at most this, and the
+// statistic is refreshed every kReprobe-th call otherwise.  Measured on model-like patterns of growing spread (round 4,
+// tools/crossover_sweep.py, profiles/r04_crossover_sweep.txt; us per launch, window / gather kernel): far 0.02: 67 / 102, 0.10: 84 /
+// 111, 0.21: 103 / 114, 0.30: 112 / 117, 0.37: 120 / 118, 0.41: 126 / 118 -- the lines cross near 0.35 (rounds 2-3 had 0.20 from
+// three flavours only, the window kernel of the time being slower)
+constexpr double kFarFractionMax = 0.33;
 constexpr unsigned kReprobe = 64, kReportEvery = 8;
 constexpr int kTH = 8, kTW = 16;
 constexpr int kWH[4] = {14, 10, 8, 7};
@@ -877,7 +879,8 @@ constexpr double kFarFractionMaxBwd = 0.05;
 // ... and msda_bwd_regions (destination-side sums, no global atomics: 0.7-0.9 ms whatever the locations) from the far fraction
 // on at which msda_bwd_tiled's far-corner atomics cost more than that (tiled: 0.02 -> 0.37 ms, 0.41 -> 0.91 ms, 0.93 -> 2.07 ms;
 // regions 0.78 / 0.71 / 0.89 ms on the same inputs: the lines cross near 0.25; profiles/r03_backward_regions.txt)
-constexpr double kFarFractionMinRegions = 0.30;
+// (round 4 sweep, tiled / regions: far 0.21: 477 / 706 us, 0.30: 655 / 688, 0.37: 801 / 664, 0.41: 922 / 642 -- they cross near 0.32)
+constexpr double kFarFractionMinRegions = 0.33;
 int backward_site_choice(const Dims& d) {
   static const int mode_env = [] { const char* e = std::getenv("MSDA_HIP_FWD_ADAPTIVE"); return e ? std::atoi(e) : 1; }();
   const CallContext ctx = t_ctx;
