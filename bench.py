@@ -64,12 +64,13 @@ from uninext_amd import ext as MSDA  # noqa: E402
 from uninext_amd import _lib  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+COLLECTIVE_TIMEOUT_S = 300
 ENC_LAYERS, DEC_LAYERS, BATCH = 6, 6, 2
 DDP_GRAD_BYTES = 640 * 1000 * 1000     # R50 + BERT-base fp32 gradients
 DDP_BUCKET_BYTES = 25 * 1024 * 1024    # torch DistributedDataParallel default bucket_cap_mb
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -81,7 +82,7 @@ def parse_args():
                     help="skip the flavours / backward / train_step / ddp measurements (profiling passes)")
     ap.add_argument("--extras-only", default="",
                     help="comma list of extras to run (flavours,backward,train,ddp,slice,matcher); default all")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def init_distributed(n_gpus):
@@ -94,8 +95,12 @@ def init_distributed(n_gpus):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import datetime
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # RCCL on ROCm
+        # a rank that dies inside a collective cannot be rescued by the others: the timeout turns that into an error
+        # instead of a hang (RCCL's default is 10 minutes)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank),   # RCCL on ROCm
+                                timeout=datetime.timedelta(seconds=COLLECTIVE_TIMEOUT_S))
     return rank, world
 
 
@@ -103,6 +108,77 @@ def barrier(world):
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
+
+
+def device_sync():
+    torch.cuda.synchronize()
+
+
+class RankSync:
+    """The ONE collective the ranks use to stay in step outside the data path: an all-reduce(MAX) of (failed, value).
+    Every rank calls `exchange` at the same points of the control flow -- also a rank whose leg has raised, which is the
+    point: a failure on one rank is learnt by all of them at the next exchange, and the leg is abandoned everywhere instead
+    of leaving the healthy ranks in a collective the failed one never enters.  It doubles as the barrier and as the
+    max-over-ranks of a time."""
+
+    def __init__(self, world, device=None):
+        self.world = world
+        if device is None and world > 1:
+            import torch.distributed as dist
+            device = "cpu" if dist.get_backend() == "gloo" else "cuda"
+        self.device = device
+
+    def exchange(self, failed=False, value=0.0, done=False):
+        """-> (any rank failed, MAX of value, every rank done, some rank done)"""
+        if self.world == 1:
+            return bool(failed), float(value), bool(done), bool(done)
+        import torch.distributed as dist
+        t = torch.tensor([1.0 if failed else 0.0, float(value), 0.0 if done else 1.0, 1.0 if done else 0.0],
+                         dtype=torch.float64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = t.cpu()
+        return bool(t[0] > 0.5), float(t[1]), bool(t[2] < 0.5), bool(t[3] > 0.5)
+
+
+def run_leg(sync, fn):
+    """Run one extra leg on every rank, collective-safe.  `fn()` returns the leg's record, or is a GENERATOR function whose
+    every `yield v` is a point where the ranks must agree: the runner exchanges (failed, v) there and sends back the
+    MAX of v over the ranks (`yield 0.0` = barrier, `t = yield local_seconds` = the job's time).  An exception on any rank,
+    in any phase, ends the leg on ALL ranks at the next exchange: {"error": ...} on the ranks that raised, {"error": "skipped:
+    another rank failed"} on the others.  A leg must not contain a collective between two yields that a rank could fail to
+    reach for a LOCAL reason (allocation, a kernel error): do the fallible set-up first, `yield`, then the collectives."""
+    import inspect
+    err, gen, result, done = None, None, None, False
+    try:
+        r = fn()
+        if inspect.isgenerator(r):
+            gen = r
+        else:
+            result, done = r, True
+    except Exception as e:  # noqa: BLE001
+        err = e
+    pending = None       # the value to send into the generator: the MAX of what the ranks yielded last
+    while True:
+        mine = 0.0
+        if err is None and gen is not None and not done:
+            try:
+                mine = float(gen.send(pending) or 0.0)
+            except StopIteration as stop:
+                result, done = stop.value, True
+            except Exception as e:  # noqa: BLE001
+                err = e
+        any_failed, agreed, all_done, some_done = sync.exchange(err is not None, mine, done)
+        if any_failed or (some_done and not all_done):
+            if gen is not None:
+                gen.close()
+            if err is not None:
+                return {"error": "%s: %s" % (type(err).__name__, err)}
+            if not any_failed:
+                return {"error": "ranks disagree on the leg's control flow"}
+            return {"error": "skipped: another rank failed in this leg"}
+        if all_done:
+            return result
+        pending = agreed
 
 
 def max_over_ranks(seconds, world, device="cuda"):
@@ -375,20 +451,20 @@ def train_step_fn(enc, dec):
 
 
 def measure_train_step(enc, dec, world, reps=10):
+    """Generator leg (run_leg): the local, fallible work sits between the yields, the ranks meet AT them."""
     step = train_step_fn(enc, dec)
     t_w = time.perf_counter()
     n_w = 0
     while n_w < 4 or (time.perf_counter() - t_w) * 1e3 < EXTRA_WARM_MS:   # (>= 4: the call sites' first locality reports are
         step()                                                              # consumed two calls later; by time: device clocks)
         n_w += 1
-    barrier(world)
-    torch.cuda.synchronize()
+    device_sync()
+    yield 0.0                                    # every rank is warm: start together
     t0 = time.perf_counter()
     for _ in range(reps):
         step()
-    torch.cuda.synchronize()
-    barrier(world)
-    dt = max_over_ranks(time.perf_counter() - t0, world) / reps
+    device_sync()
+    dt = (yield time.perf_counter() - t0) / reps     # the job's time = the slowest rank's
     return {"ms_per_step": 1e3 * dt, "frames_per_s": world * BATCH / dt,
             "workload": "BASELINE configs[4] per-GPU share at the training shapes (bs 2, 800x1344: S=%d; decoder Lq=%d): "
                         "6 encoder + 6 decoder MSDeformAttn forward AND backward calls through MSDeformAttnFunction "
@@ -396,14 +472,28 @@ def measure_train_step(enc, dec, world, reps=10):
             "kernels": {"forward_last": _lib.last_kernel("forward"), "backward_last": _lib.last_kernel("backward")}}
 
 
+def _side_stream():
+    return torch.cuda.Stream()
+
+
+def _ddp_buckets(n_buckets, n_el):
+    return [torch.randn(n_el, device="cuda") for _ in range(n_buckets)]
+
+
 def measure_ddp(enc, dec, world, reps=5):
     """fp32 gradient all-reduce (mean) in DDP-sized buckets over RCCL, alone and overlapped with the op's backward
-    launches (side stream), as DistributedDataParallel overlaps it with autograd."""
+    launches (side stream), as DistributedDataParallel overlaps it with autograd.  Generator leg (run_leg): buffers and
+    the autograd step are set up (and the step run once) BEFORE the first yield, so that a rank that cannot do so never
+    leaves the others inside an all-reduce."""
     import torch.distributed as dist
     n_el = DDP_BUCKET_BYTES // 4
     n_buckets = (DDP_GRAD_BYTES + DDP_BUCKET_BYTES - 1) // DDP_BUCKET_BYTES
-    buckets = [torch.randn(n_el, device="cuda") for _ in range(n_buckets)]
-    comm = torch.cuda.Stream()
+    buckets = _ddp_buckets(n_buckets, n_el)
+    comm = _side_stream()
+    step = train_step_fn(enc, dec)
+    step()
+    device_sync()
+    yield 0.0                                    # every rank holds its buckets and has run the step once
 
     def allreduce_all():
         for b in buckets:
@@ -412,16 +502,14 @@ def measure_ddp(enc, dec, world, reps=5):
 
     def timed(fn):
         fn()
-        barrier(world)
-        torch.cuda.synchronize()
+        device_sync()
+        yield 0.0
         t0 = time.perf_counter()
         for _ in range(reps):
             fn()
-        torch.cuda.synchronize()
-        barrier(world)
-        return 1e3 * max_over_ranks(time.perf_counter() - t0, world) / reps
-
-    step = train_step_fn(enc, dec)
+        device_sync()
+        t = yield time.perf_counter() - t0
+        return 1e3 * t / reps
 
     def overlapped():
         comm.wait_stream(torch.cuda.current_stream())
@@ -430,13 +518,14 @@ def measure_ddp(enc, dec, world, reps=5):
         step()
         torch.cuda.current_stream().wait_stream(comm)
 
-    ar = timed(allreduce_all)
-    st = timed(step)
-    ov = timed(overlapped)
+    ar = yield from timed(allreduce_all)
+    st = yield from timed(step)
+    ov = yield from timed(overlapped)
     nbytes = n_buckets * DDP_BUCKET_BYTES
     return {"allreduce_ms": ar, "bytes": nbytes, "buckets": n_buckets, "bucket_bytes": DDP_BUCKET_BYTES,
             "busbw_GBs": 2.0 * (world - 1) / world * nbytes / (ar * 1e-3) / 1e9,
-            "op_fwd_bwd_ms": st, "overlapped_ms": ov, "backend": "nccl (RCCL over xGMI)"}
+            "op_fwd_bwd_ms": st, "overlapped_ms": ov, "backend": "%s (RCCL over xGMI)" % dist.get_backend(),
+            "rccl_ranks": dist.get_world_size()}
 
 
 def measure_matcher(reps=20):
@@ -582,11 +671,16 @@ def cpu_baseline(flavour):
                       % (runs, med["encoder"], med["decoder"], threads, ncpu, sorted(probe))}
 
 
-def main():
-    args = parse_args()
+def new_event_pairs(n):
+    return [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+
+
+def main(argv=None):
+    args = parse_args(argv)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU implementation)")
     rank, world = init_distributed(args.gpus)
+    sync = RankSync(world)
     _lib.load()
     enc, dec = build_inputs(args.flavour, rank)
     S = enc[0]["value"].shape[1]
@@ -602,55 +696,64 @@ def main():
     while (time.perf_counter() - t_pre) * 1e3 < PREWARM_MS:
         for _ in range(8):
             run_step(enc, dec)
-        torch.cuda.synchronize()
+        device_sync()
     for _ in range(max(args.warmup, 0)):
         run_step(enc, dec)
     call(enc[0], 1)
     enc_kernel = _lib.last_kernel("forward")   # the kernel the encoder launches take (decoder calls may differ)
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    events = new_event_pairs(args.steps)
 
     barrier(world)
-    torch.cuda.synchronize()
+    device_sync()
     t0 = time.perf_counter()
     for k in range(args.steps):
         # the encoder launches of every EVENT_EVERY-th step are bracketed by HIP events (an event record drains the queue:
         # bracketing every step costs ~2 % of the step it measures)
         run_step(enc, dec, events[k] if k % EVENT_EVERY == 0 else None)
-    torch.cuda.synchronize()
+    device_sync()
     barrier(world)
-    elapsed = max_over_ranks(time.perf_counter() - t0, world)
+    elapsed = max_over_ranks(time.perf_counter() - t0, world, sync.device or "cuda")
 
     extras = {}
     want = set(args.extras_only.split(",")) if args.extras_only else {"flavours", "backward", "train", "ddp", "slice", "matcher"}
-    if not args.no_extras:   # every rank takes part (collectives inside), rank 0 reports
-        def extra(key, fn):      # an extra that fails must not take the contract line with it
-            try:
-                extras[key] = fn()
-            except Exception as e:  # noqa: BLE001
-                extras[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if not args.no_extras:
+        # Every rank walks the SAME list of legs and meets the others in run_leg's exchanges (one per leg, plus one per
+        # `yield` of a generator leg): an extra that fails on one rank takes neither the contract line nor the other
+        # ranks with it.  Legs marked rank-0-only run as a no-op elsewhere; the exchange still happens.
+        def extra(key, fn, rank0_only=False):
+            rec = run_leg(sync, fn if (rank == 0 or not rank0_only) else (lambda: None))
+            if isinstance(rec, dict) and "error" in rec:
                 try:
                     _lib.set_variant("forward", "auto")
                     _lib.set_variant("backward", "auto")
                 except Exception:  # noqa: BLE001
                     pass
+            if rank == 0 or not rank0_only:
+                extras[key] = rec
         if "flavours" in want:
             extra("flavours", lambda: measure_flavours(rank))
             if args.flavour == "model":
                 extra("forward_kernels", lambda: measure_forward_kernels(enc))
+        tr, have_inputs = {}, False
         if want & {"backward", "train", "ddp"}:
             # config 5's legs run on the TRAINING shapes (three input sets per call kind; a layer index i takes set i % 3)
-            tenc, tdec = build_train_inputs(args.flavour, rank)
-            tenc6, tdec6 = [tenc[i % 3] for i in range(ENC_LAYERS)], [tdec[i % 3] for i in range(DEC_LAYERS)]
-        if "backward" in want:
-            extra("backward", lambda: measure_backward(tenc, tdec))
-        if "train" in want:
-            extra("train_step", lambda: measure_train_step(tenc6, tdec6, world))
-        if "ddp" in want and world > 1:
-            extra("ddp", lambda: measure_ddp(tenc6, tdec6, world))
-        if "slice" in want and rank == 0:
-            extra("model_slice", measure_model_slice)
-        if "matcher" in want and rank == 0:
-            extra("matcher", measure_matcher)
+            def train_inputs():
+                tenc, tdec = build_train_inputs(args.flavour, rank)
+                tr.update(enc=tenc, dec=tdec, enc6=[tenc[i % 3] for i in range(ENC_LAYERS)],
+                          dec6=[tdec[i % 3] for i in range(DEC_LAYERS)])
+                return {"ok": True}
+            extra("_train_inputs", train_inputs)
+            have_inputs = "error" not in extras.pop("_train_inputs")   # (the same on every rank: run_leg agrees on it)
+        if "backward" in want and have_inputs:
+            extra("backward", lambda: measure_backward(tr["enc"], tr["dec"]))
+        if "train" in want and have_inputs:
+            extra("train_step", lambda: measure_train_step(tr["enc6"], tr["dec6"], world))
+        if "ddp" in want and world > 1 and have_inputs:
+            extra("ddp", lambda: measure_ddp(tr["enc6"], tr["dec6"], world))
+        if "slice" in want:
+            extra("model_slice", measure_model_slice, rank0_only=True)
+        if "matcher" in want:
+            extra("matcher", measure_matcher, rank0_only=True)
 
     if rank == 0:
         sampled = events[::EVENT_EVERY]
@@ -713,6 +816,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.flavour)
         print(json.dumps(out), flush=True)
 
+    # every rank is through its legs (rank 0 also through the rank-0-only ones and the line) before the group goes away
+    sync.exchange()
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
