@@ -43,6 +43,8 @@ Extra objects on the JSON line (all measured in this run, after the timed region
                 step: ms per part, frames/s of the slice (an UPPER bound on the model: the backbone and the rest are plain
                 PyTorch-ROCm), and the share of it that the step's sampling kernels are.  rccl_ranks / busbw (top level): the
                 world size the process group reports and the DDP leg's bus bandwidth.
+  reference_module_on_top  the six encoder calls of a pass made WITHOUT call sites (the reference's unmodified module on top,
+                INTEGRATION.md option A: sites derived from the call ordinal, one geometry check per pass) beside explicit sites.
   cpu_baseline  the reference's CPU path (ms_deform_attn_core_pytorch, restated in oracle/msda_gridsample.py)
                 timed on this box's host cores on a bounded sample, rank 0 at N = 1 only.
 """
@@ -81,7 +83,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the flavours / backward / train_step / ddp measurements (profiling passes)")
     ap.add_argument("--extras-only", default="",
-                    help="comma list of extras to run (flavours,backward,train,ddp,slice,matcher); default all")
+                    help="comma list of extras to run (flavours,backward,train,ddp,slice,matcher,refmodule); default all")
     return ap.parse_args(argv)
 
 
@@ -528,6 +530,46 @@ def measure_ddp(enc, dec, world, reps=5):
             "rccl_ranks": dist.get_world_size()}
 
 
+def measure_reference_module_on_top(enc, reps=20):
+    """INTEGRATION.md option A: the reference's unmodified MSDeformAttn on top calls the operator with no call site
+    (ops/modules/ms_deform_attn.py:113).  The six encoder calls of a forward pass made that way -- a spatial_shapes tensor
+    rebuilt per pass as Deformable-DETR does (one geometry check = one device-to-host copy per pass), sites derived from the
+    call ordinal (uninext_amd.ext) -- beside the same calls with explicit sites (what this repository's module passes)."""
+    from uninext_amd import ext as _ext
+    n = len(enc)
+
+    def derived_pass():
+        sh, lsi = enc[0]["shapes"].clone(), enc[0]["lsi"].clone()
+        sites, kernels = [], []
+        for x in enc:
+            MSDA.ms_deform_attn_forward(x["value"], sh, lsi, x["loc"], x["attn"], 64)
+            sites.append(_ext.last_call_site())
+            kernels.append(_lib.last_kernel("forward"))
+        return sites, kernels
+
+    def explicit_pass():
+        for i, x in enumerate(enc):
+            call(x, 1 + i)
+
+    def wall(fn):
+        for _ in range(4):
+            fn()
+        device_sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        device_sync()
+        return 1e3 * (time.perf_counter() - t0) / reps
+
+    _ext.reset_auto_sites()
+    t_derived = wall(derived_pass)
+    sites, kernels = derived_pass()
+    t_explicit = wall(explicit_pass)
+    return {"derived_sites_ms_per_pass": t_derived, "explicit_sites_ms_per_pass": t_explicit, "encoder_calls_per_pass": n,
+            "derived_sites": sites, "kernels": kernels,
+            "note": "wall clock of %d encoder-shaped forward calls + one spatial_shapes rebuild and geometry check per pass" % n}
+
+
 def measure_matcher(reps=20):
     """simOTA assignment (dd/matcher.py:286-447, the matcher of every decoder layer under MODEL.OTA) at config 5's shapes: bs 2,
     900 queries, 256 tokens, 7 + 19 targets -- the two HIP kernels of include/ota_hip.h with their one host copy per call beside
@@ -715,7 +757,7 @@ def main(argv=None):
     elapsed = max_over_ranks(time.perf_counter() - t0, world, sync.device or "cuda")
 
     extras = {}
-    want = set(args.extras_only.split(",")) if args.extras_only else {"flavours", "backward", "train", "ddp", "slice", "matcher"}
+    want = set(args.extras_only.split(",")) if args.extras_only else {"flavours", "backward", "train", "ddp", "slice", "matcher", "refmodule"}
     if not args.no_extras:
         # Every rank walks the SAME list of legs and meets the others in run_leg's exchanges (one per leg, plus one per
         # `yield` of a generator leg): an extra that fails on one rank takes neither the contract line nor the other
@@ -750,6 +792,8 @@ def main(argv=None):
             extra("train_step", lambda: measure_train_step(tr["enc6"], tr["dec6"], world))
         if "ddp" in want and world > 1 and have_inputs:
             extra("ddp", lambda: measure_ddp(tr["enc6"], tr["dec6"], world))
+        if "refmodule" in want:
+            extra("reference_module_on_top", lambda: measure_reference_module_on_top(enc), rank0_only=True)
         if "slice" in want:
             extra("model_slice", measure_model_slice, rank0_only=True)
         if "matcher" in want:

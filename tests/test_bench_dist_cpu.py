@@ -117,6 +117,7 @@ def _main_worker(rank, world, port, fail_rank, fail_where, out):
     bench.measure_flavours = lambda r: {"stub": True}
     bench.measure_forward_kernels = lambda enc: {"far_fraction": {"model": 0.02, "wide": 0.4}}
     bench.measure_backward = lambda e, d: {"stub": True}
+    bench.measure_reference_module_on_top = lambda e: {"stub": True}
     bench.train_step_fn = train_step_fn
     bench.measure_model_slice = rank0_leg
     bench.measure_matcher = rank0_leg

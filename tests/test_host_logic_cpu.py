@@ -161,7 +161,7 @@ def test_call_sites_nest_and_travel_with_the_autograd_function():
     real_backward = ext.ms_deform_attn_backward
 
     def spy(*args):
-        recorded.append(ext.current_call_site())
+        recorded.append(ext.explicit_call_site())
         return real_backward(*args)
 
     ext.ms_deform_attn_backward, saved = spy, ext.ms_deform_attn_backward
@@ -173,3 +173,66 @@ def test_call_sites_nest_and_travel_with_the_autograd_function():
         ext.ms_deform_attn_backward = saved
     assert recorded == [5]
     assert value.grad is not None and loc.grad is not None and attn.grad is not None
+    # a forward outside of every block records NO site: its backward is matched to it by the derived-site rules instead
+    value.grad = loc.grad = attn.grad = None
+    ext.ms_deform_attn_backward, saved = spy, ext.ms_deform_attn_backward
+    try:
+        MSDeformAttnFunction.apply(value, shapes, lsi, loc, attn, 64).sum().backward()
+    finally:
+        ext.ms_deform_attn_backward = saved
+    assert recorded == [5, None]
+
+
+def test_derived_call_sites_for_callers_that_pass_none():
+    """VERDICT r04 item 4 (INTEGRATION.md option A): the reference's unmodified MSDeformAttn calls the operator with no notion
+    of a call site (ops/modules/ms_deform_attn.py:113).  uninext_amd.ext derives one from the call ordinal since the pass's
+    spatial_shapes tensor object was first seen (Deformable-DETR builds it once per forward and hands it to every layer,
+    dino.py:338,363): six encoder layers = six sites, the same six in every pass; a backward call finds its forward's site
+    through the storage of sampling_loc; decoder-shaped calls take no context and do not count."""
+    import torch
+
+    from uninext_amd import ext
+
+    class Lib:
+        def __init__(self):
+            self.calls = []
+
+        def msda_hip_set_call_context(self, site, flags):
+            self.calls.append((site, flags))
+
+    lib, S = Lib(), 2048
+    real = ext._geometry_checked
+    ext._geometry_checked = lambda *a: True
+    ext.reset_auto_sites()
+    try:
+        def ctx(sh, loc, Lq=S, backward=False):
+            ext._set_call_context(lib, torch.float32, sh, None, S, 32, 4, Lq, 4, loc, backward=backward)
+
+        for _ in range(2):                                        # two forward + backward passes of a six-layer encoder
+            sh = torch.zeros(4, 2, dtype=torch.long)              # rebuilt per pass, as the reference does
+            locs = [torch.zeros(8) for _ in range(6)]             # alive until their backward, as autograd keeps them
+            for i, l in enumerate(locs):
+                ctx(sh, l)
+                assert ext.last_call_site() == ext.AUTO_SITE_BASE + i
+                ctx(sh, torch.zeros(3), Lq=900)                   # the decoder's calls in between: no context, no ordinal
+            for l in reversed(locs):
+                ctx(sh, l, backward=True)
+        want = [ext.AUTO_SITE_BASE + i for i in range(6)]
+        assert [c[0] for c in lib.calls] == (want + want[::-1]) * 2
+        assert all(c[1] == ext.CTX_GEOMETRY_CHECKED for c in lib.calls)
+        ctx(sh, torch.zeros(5), backward=True)                    # a backward whose forward is unknown: history-free
+        assert lib.calls[-1][0] == -1
+        with ext.call_site(5):                                    # an explicit block wins and does not disturb the ordinal
+            ctx(sh, locs[0])
+        assert lib.calls[-1][0] == 5
+        ctx(sh, locs[0])
+        assert lib.calls[-1][0] == ext.AUTO_SITE_BASE + 6
+        sh._version_bump = sh.add_(1)                             # the same object, modified in place: a new pass
+        ctx(sh, locs[0])
+        assert lib.calls[-1][0] == ext.AUTO_SITE_BASE
+        for i in range(1, 40):                                    # more calls than slots: wraps around
+            ctx(sh, locs[0])
+        assert lib.calls[-1][0] == ext.AUTO_SITE_BASE + 39 % ext.AUTO_SITES
+    finally:
+        ext._geometry_checked = real
+        ext.reset_auto_sites()

@@ -178,6 +178,57 @@ def test_forward_choice_is_per_call_site_and_repeatable(dev, api):
         assert torch.equal(am, bm) and torch.equal(au, bu)
 
 
+def test_reference_style_layers_without_a_call_site_get_one_each(dev, api):
+    """VERDICT r04 item 4 (INTEGRATION.md option A): a stand-in for the reference's UNMODIFIED stack -- an autograd Function that
+    only knows MSDA.ms_deform_attn_forward / _backward (ops/functions/ms_deform_attn_func.py:21-40), called from six "encoder
+    layers" per forward pass with the pass's own spatial_shapes tensor (dino.py:338,363), no call_site() anywhere.  Layers 0..3
+    sample near their queries, layers 4..5 all over the image: uninext_amd.ext derives six call sites from the call ordinal,
+    every layer converges on ITS kernel, and each backward call follows the forward reports of its own layer."""
+    from uninext_amd import ext, workloads
+    MSDA, lib = api
+    seen = {"fwd": [], "bwd": []}
+
+    class PlainFunction(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, value, shapes, lsi, loc, attn, step):
+            ctx.step = step
+            out = MSDA.ms_deform_attn_forward(value, shapes, lsi, loc, attn, step)
+            seen["fwd"].append((ext.last_call_site(), lib.last_kernel("forward")))
+            ctx.save_for_backward(value, shapes, lsi, loc, attn)
+            return out
+
+        @staticmethod
+        def backward(ctx, grad_output):
+            value, shapes, lsi, loc, attn = ctx.saved_tensors
+            gv, gl, ga = MSDA.ms_deform_attn_backward(value, shapes, lsi, loc, attn, grad_output.contiguous(), ctx.step)
+            seen["bwd"].append((ext.last_call_site(), lib.last_kernel("backward")))
+            return gv, None, None, gl, ga, None
+
+    flav = ["model"] * 4 + ["uniform"] * 2
+    xs = [_inputs(f, workloads.R50_LEVELS_INFER, 81 + i, dev) for i, f in enumerate(flav)]
+    ext.reset_auto_sites()
+    for p in range(5):
+        shapes, lsi = xs[0]["shapes"].clone(), xs[0]["lsi"].clone()          # one tensor object per pass, shared by the layers
+        seen["fwd"].clear(); seen["bwd"].clear()
+        train = p == 4
+        outs = []
+        for x in xs:
+            v, l, a = ((x[k].clone().requires_grad_(True) if train else x[k]) for k in ("value", "loc", "attn"))
+            outs.append(PlainFunction.apply(v, shapes, lsi, l, a, 64))
+        assert [s for s, _ in seen["fwd"]] == [ext.AUTO_SITE_BASE + i for i in range(6)], seen["fwd"]
+        if p >= 3:                                                          # (a site's reports are consumed two calls later)
+            assert [k for _, k in seen["fwd"]] == ["msda_fwd_win"] * 4 + ["msda_fwd_lg3"] * 2, seen["fwd"]
+        if train:
+            torch.autograd.backward(outs, [torch.ones_like(o) for o in outs])
+            got = dict(seen["bwd"])                                          # autograd's order is its own: by site
+            assert sorted(got) == [ext.AUTO_SITE_BASE + i for i in range(6)], seen["bwd"]
+            for i in range(6):
+                assert got[ext.AUTO_SITE_BASE + i] == ("msda_bwd_win" if i < 4 else "msda_bwd_regions"), seen["bwd"]
+    # the outputs are those of the pinned kernels (the choice never changes a result beyond summation order)
+    for x, o, k in zip(xs, outs, ["msda_fwd_win"] * 4 + ["msda_fwd_lg3"] * 2):
+        assert torch.equal(o.detach(), _fwd(MSDA, lib, x, k))
+
+
 def test_forward_choice_is_pinned_without_context_or_when_determinism_is_asked_for(dev, api):
     """A plain C-ABI call (no context), unverifiable geometry (sum H*W != spatial_size: legal for the reference operator,
     not for the window kernels -- ADVICE r02) and torch.use_deterministic_algorithms(True) all take the gather kernel."""

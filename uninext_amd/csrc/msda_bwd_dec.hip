@@ -100,130 +100,97 @@ msda_bwd_dec(const float* __restrict__ grad_out, const float* __restrict__ value
   }
 
   const int64_t pix_stride = (int64_t)M * 32;
-  // Round 4: a pair's 32 location floats, 16 attention weights and 32 upstream gradients arrive LANE-PARALLEL, one load each per
-  // lane, a query AHEAD of their use -- they used to be 12 same-address loads per level in front of the corner loads that depend
-  // on them, i.e. two dependent memory round trips per level step (~8 us each under this kernel's own atomics; the launch is a
-  // latency chain: fewer, longer slices are slower -- 88 / 94 / 102 / 112 us at 16 / 12 / 8 / 6 slices).  MSDA_BWD_DEC_AHEAD=0: A/B.
-#ifndef MSDA_BWD_DEC_AHEAD
-#define MSDA_BWD_DEC_AHEAD 1
-#endif
-  float locv_n = 0.f, attv_n = 0.f, g_n = 0.f;             // the NEXT query's
-  auto fetch_pair = [&](int q) __attribute__((always_inline)) {
-    if (q < q1) {
-      const int64_t pr = ((int64_t)b * d.Lq + q) * M + m;
-      locv_n = loc[pr * 32 + lane];
-      attv_n = attn[pr * 16 + (lane & 15)];
+  // Work unit = (query, level): a half wave takes the slice's units u = hw, hw + 32, ... in order (u = 4 x query + level).
+  // Round 4 walked a half wave through the FOUR levels of its query -- 69 queries on 32 half waves = 3 queries x 4 dependent
+  // level steps for the slowest half wave, 12 memory round trips in a chain that the launch waits for (66.8 % of the wave
+  // cycles waiting, profiles/r04_sq_pmc.txt).  Units balance the same work to ceil(276 / 32) = 9 steps.  A unit's 8 location
+  // floats, 4 attention weights and 32 upstream gradients arrive LANE-PARALLEL (one load each per lane), one unit AHEAD of
+  // their use, so that a step is ONE memory round trip: the 16 corner loads.
+  const int nunits = (q1 - q0) * 4;
+  const uint32_t ps32 = (uint32_t)M * 32u;
+  const __amdgpu_buffer_rsrc_t vsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(value), 0, (int)((uint32_t)d.N * (uint32_t)d.S * ps32 * 4u), 0x00020000);
+  float locv_n = 0.f, attv_n = 0.f, g_n = 0.f;             // the NEXT unit's
+  auto fetch_unit = [&](int u) __attribute__((always_inline)) {
+    if (u < nunits) {
+      const int64_t pr = ((int64_t)b * d.Lq + q0 + (u >> 2)) * M + m;
+      const int l = u & 3;
+      locv_n = loc[pr * 32 + l * 8 + (lane & 7)];
+      attv_n = attn[pr * 16 + l * 4 + (lane & 3)];
       g_n = grad_out[pr * 32 + lane];
     } else {
       locv_n = 0.f; attv_n = 0.f; g_n = 0.f;
     }
   };
-  if (MSDA_BWD_DEC_AHEAD) fetch_pair(q0 + hw);
-  for (int q = q0 + hw; ; q += kDT / 32) {
+  fetch_unit(hw);
+  for (int u = hw; ; u += kDT / 32) {
     // the two halves of a wave run in lock step: a half past the end idles through the loop with `live` off
-    const bool live = q < q1;
+    const bool live = u < nunits;
     if (!__ballot(live)) break;
-    const int64_t pair = ((int64_t)b * d.Lq + (live ? q : q0)) * M + m;
-    float* const ga_p = grad_attn + pair * 16;              // this pair's 16 + 32 outputs
-    float* const gl_p = grad_loc + pair * 32;
-    const float locv = locv_n, attv = attv_n;
-    const float g = MSDA_BWD_DEC_AHEAD ? g_n : (live ? grad_out[pair * 32 + lane] : 0.f);
-    if (MSDA_BWD_DEC_AHEAD) fetch_pair(q + kDT / 32);
-    // a level = its four points: samples from the broadcast locations, 16 corner loads issued (`issue`), then the gradients and the
-    // adds (`consume`).  MSDA_BWD_DEC_DEPTH=2 keeps TWO levels in flight (the corner loads of level l + 1 travel while level l is
-    // consumed): measured and not the default -- it needs ~200 registers, i.e. 512 or 768 threads (84-86 us against 80 at 1024
-    // threads and one level; 112 us at 1024 threads with its spills; profiles/r04_backward_decoder.txt).
-#ifndef MSDA_BWD_DEC_DEPTH
-#define MSDA_BWD_DEC_DEPTH 1
-#endif
-    // (the state of a level in flight is kept small -- 40 registers: fractions, corner, weight, 16 values; validity flags,
-    // complements and offsets are re-derived when it is consumed; 32-bit element offsets: dec_backward_ok)
-    struct Lv { float lh[4], lw[4], a[4], v[4][4]; int h_low[4], w_low[4]; bool in[4]; };
-    const uint32_t ps32 = (uint32_t)M * 32u;
-    const __amdgpu_buffer_rsrc_t vsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(value), 0, (int)((uint32_t)d.N * (uint32_t)d.S * ps32 * 4u), 0x00020000);
-    auto issue = [&](auto ltag, Lv& L) __attribute__((always_inline)) {
-      constexpr int l = decltype(ltag)::value;
-      const int Hl = H[l], Wl = W[l];
-      const uint32_t lvl_off = ((uint32_t)b * (uint32_t)d.S + (uint32_t)S0[l]) * ps32 + (uint32_t)m * 32u + (uint32_t)lane;
+    const int l = u & 3;                                     // (per HALF wave: the halves of a wave work on two levels)
+    const bool l0 = (l & 1) != 0, l1 = (l & 2) != 0;
+    const int Hl = l1 ? (l0 ? H[3] : H[2]) : (l0 ? H[1] : H[0]), Wl = l1 ? (l0 ? W[3] : W[2]) : (l0 ? W[1] : W[0]);
+    const int Sl = l1 ? (l0 ? S0[3] : S0[2]) : (l0 ? S0[1] : S0[0]);
+    const int64_t pair = ((int64_t)b * d.Lq + q0 + (live ? (u >> 2) : 0)) * M + m;
+    const float locv = locv_n, attv = attv_n, g = g_n;
+    fetch_unit(u + kDT / 32);
+    const uint32_t lvl_off = ((uint32_t)b * (uint32_t)d.S + (uint32_t)Sl) * ps32 + (uint32_t)m * 32u + (uint32_t)lane;
+    // accumulator rows of this level (none on levels 0 and 1)
+    const int rows_l = use_lds ? (l == 3 ? rows3 : l == 2 ? rows2 : 0) : 0;
+    const int slot0 = l == 3 ? 0 : base2;
+    // ---- issue: the four samples of the unit from the broadcast locations, their 16 corner loads ------------------------
+    float lh[4], lw[4], a[4], v[4][4];
+    int h_low[4], w_low[4];
+    bool in[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int64_t si = pair * 16 + l * 4 + k;
-        Sample<float> t;
-        if (MSDA_BWD_DEC_AHEAD) {   // (half-wave broadcasts: lanes 2 i, 2 i + 1 of the half hold sample i's x, y; lane i its weight)
-          L.a[k] = __shfl(attv, l * 4 + k, 32);
-          t = make_sample<float>(__shfl(locv, 2 * (l * 4 + k), 32), __shfl(locv, 2 * (l * 4 + k) + 1, 32), Hl, Wl);
-        } else {
-          L.a[k] = attn[si];
-          t = make_sample<float>(loc[si * 2], loc[si * 2 + 1], Hl, Wl);
-        }
-        L.in[k] = live && t.in_range;
-        L.lh[k] = t.lh; L.lw[k] = t.lw; L.h_low[k] = t.h_low; L.w_low[k] = t.w_low;
-        // raw buffer loads: one 32-bit byte offset per corner, dead corners at an out-of-range offset (they return 0)
-        const uint32_t o1 = (lvl_off + (uint32_t)(t.h_low * Wl + t.w_low) * ps32) * 4u;   // (h_low, w_low = 0 for samples out of range)
-        const uint32_t rowb = (uint32_t)Wl * ps32 * 4u, pxb = ps32 * 4u;
-        L.v[k][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(vsrc, (L.in[k] && t.ok1) ? o1 : kOobOffset, 0, 0));
-        L.v[k][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(vsrc, (L.in[k] && t.ok2) ? o1 + pxb : kOobOffset, 0, 0));
-        L.v[k][2] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(vsrc, (L.in[k] && t.ok3) ? o1 + rowb : kOobOffset, 0, 0));
-        L.v[k][3] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(vsrc, (L.in[k] && t.ok4) ? o1 + rowb + pxb : kOobOffset, 0, 0));
-      }
-    };
-    auto consume = [&](auto ltag, const Lv& L) __attribute__((always_inline)) {
-      constexpr int l = decltype(ltag)::value;
-      const int Hl = H[l], Wl = W[l];
-      const uint32_t lvl_off = ((uint32_t)b * (uint32_t)d.S + (uint32_t)S0[l]) * ps32 + (uint32_t)m * 32u + (uint32_t)lane;
-      // accumulator rows of this level (none on levels 0 and 1)
-      const int rows_l = use_lds ? (l == 3 ? rows3 : l == 2 ? rows2 : 0) : 0;
-      const int slot0 = l == 3 ? 0 : base2;
+    for (int k = 0; k < 4; ++k) {   // (half-wave broadcasts: lanes 2 k, 2 k + 1 of the half hold point k's x, y; lane k its weight)
+      a[k] = __shfl(attv, k, 32);
+      const Sample<float> t = make_sample<float>(__shfl(locv, 2 * k, 32), __shfl(locv, 2 * k + 1, 32), Hl, Wl);
+      in[k] = live && t.in_range;
+      lh[k] = t.lh; lw[k] = t.lw; h_low[k] = t.h_low; w_low[k] = t.w_low;
+      // raw buffer loads: one 32-bit byte offset per corner, dead corners at an out-of-range offset (they return 0)
+      const uint32_t o1 = (lvl_off + (uint32_t)(t.h_low * Wl + t.w_low) * ps32) * 4u;   // (h_low, w_low = 0 for samples out of range)
+      const uint32_t rowb = (uint32_t)Wl * ps32 * 4u, pxb = ps32 * 4u;
+      v[k][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(vsrc, (in[k] && t.ok1) ? o1 : kOobOffset, 0, 0));
+      v[k][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(vsrc, (in[k] && t.ok2) ? o1 + pxb : kOobOffset, 0, 0));
+      v[k][2] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(vsrc, (in[k] && t.ok3) ? o1 + rowb : kOobOffset, 0, 0));
+      v[k][3] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(vsrc, (in[k] && t.ok4) ? o1 + rowb + pxb : kOobOffset, 0, 0));
+    }
+    // ---- consume: the gradients and the adds ----------------------------------------------------------------------------
+    float* const ga_p = grad_attn + pair * 16 + l * 4;        // this unit's 4 + 8 outputs
+    float* const gl_p = grad_loc + pair * 32 + l * 8;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        float pa = 0.f, pw = 0.f, ph = 0.f;
-        if (__ballot(L.in[k])) {                             // wave-uniform (the sums need every lane of the half)
-          if (L.in[k]) {
-            const int h_low = L.h_low[k], w_low = L.w_low[k];
-            const float lh = L.lh[k], lw = L.lw[k], hh = 1.f - lh, hw = 1.f - lw;
-            const bool tp = h_low >= 0, bt = h_low + 1 <= Hl - 1, lf = w_low >= 0, rt = w_low + 1 <= Wl - 1;   // (make_sample's rule)
-            const bool ok1 = tp && lf, ok2 = tp && rt, ok3 = bt && lf, ok4 = bt && rt;
-            const float tgv = g * L.a[k];
-            const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-            // (all four in 32-bit arithmetic: with h_low or w_low = -1 the top-left offset wraps and its neighbours wrap back)
-            const uint32_t o1 = lvl_off + (uint32_t)(h_low * Wl + w_low) * ps32, o2 = o1 + ps32, o3 = o1 + (uint32_t)Wl * ps32, o4 = o3 + ps32;
-            // a corner on an accumulator row: fixed-point LDS add; otherwise the direct full-line atomic
-            const bool top_acc = h_low >= 0 && h_low < rows_l, bot_acc = h_low + 1 < rows_l;
-            int* const at = acc + (slot0 + h_low * Wl + w_low) * 32 + lane;
-            if (ok1) { if (top_acc) atomicAdd(at, __float2int_rn(w1 * tgv * scale)); else atomic_add(grad_value + o1, w1 * tgv); }
-            if (ok2) { if (top_acc) atomicAdd(at + 32, __float2int_rn(w2 * tgv * scale)); else atomic_add(grad_value + o2, w2 * tgv); }
-            if (ok3) { if (bot_acc) atomicAdd(at + Wl * 32, __float2int_rn(w3 * tgv * scale)); else atomic_add(grad_value + o3, w3 * tgv); }
-            if (ok4) { if (bot_acc) atomicAdd(at + Wl * 32 + 32, __float2int_rn(w4 * tgv * scale)); else atomic_add(grad_value + o4, w4 * tgv); }
-            pa = g * (w1 * L.v[k][0] + w2 * L.v[k][1] + w3 * L.v[k][2] + w4 * L.v[k][3]);
-            pw = tgv * (hh * (L.v[k][1] - L.v[k][0]) + lh * (L.v[k][3] - L.v[k][2]));
-            ph = tgv * (hw * (L.v[k][2] - L.v[k][0]) + lw * (L.v[k][3] - L.v[k][1]));
-          }
-          pa = half_sum(pa);
-          pw = half_sum(pw);
-          ph = half_sum(ph);
+    for (int k = 0; k < 4; ++k) {
+      float pa = 0.f, pw = 0.f, ph = 0.f;
+      if (__ballot(in[k])) {                                 // wave-uniform (the sums need every lane of the half)
+        if (in[k]) {
+          const float hh = 1.f - lh[k], hw_ = 1.f - lw[k];
+          const bool tp = h_low[k] >= 0, bt = h_low[k] + 1 <= Hl - 1, lf = w_low[k] >= 0, rt = w_low[k] + 1 <= Wl - 1;   // (make_sample's rule)
+          const bool ok1 = tp && lf, ok2 = tp && rt, ok3 = bt && lf, ok4 = bt && rt;
+          const float tgv = g * a[k];
+          const float w1 = hh * hw_, w2 = hh * lw[k], w3 = lh[k] * hw_, w4 = lh[k] * lw[k];
+          // (all four in 32-bit arithmetic: with h_low or w_low = -1 the top-left offset wraps and its neighbours wrap back)
+          const uint32_t o1 = lvl_off + (uint32_t)(h_low[k] * Wl + w_low[k]) * ps32, o2 = o1 + ps32, o3 = o1 + (uint32_t)Wl * ps32, o4 = o3 + ps32;
+          // a corner on an accumulator row: fixed-point LDS add; otherwise the direct full-line atomic
+          const bool top_acc = h_low[k] >= 0 && h_low[k] < rows_l, bot_acc = h_low[k] + 1 < rows_l;
+          int* const at = acc + (slot0 + h_low[k] * Wl + w_low[k]) * 32 + lane;
+          if (ok1) { if (top_acc) atomicAdd(at, __float2int_rn(w1 * tgv * scale)); else atomic_add(grad_value + o1, w1 * tgv); }
+          if (ok2) { if (top_acc) atomicAdd(at + 32, __float2int_rn(w2 * tgv * scale)); else atomic_add(grad_value + o2, w2 * tgv); }
+          if (ok3) { if (bot_acc) atomicAdd(at + Wl * 32, __float2int_rn(w3 * tgv * scale)); else atomic_add(grad_value + o3, w3 * tgv); }
+          if (ok4) { if (bot_acc) atomicAdd(at + Wl * 32 + 32, __float2int_rn(w4 * tgv * scale)); else atomic_add(grad_value + o4, w4 * tgv); }
+          pa = g * (w1 * v[k][0] + w2 * v[k][1] + w3 * v[k][2] + w4 * v[k][3]);
+          pw = tgv * (hh * (v[k][1] - v[k][0]) + lh[k] * (v[k][3] - v[k][2]));
+          ph = tgv * (hw_ * (v[k][2] - v[k][0]) + lw[k] * (v[k][3] - v[k][1]));
         }
-        if (live && lane == 0) {
-          ga_p[l * 4 + k] = pa;
-          gl_p[2 * (l * 4 + k)] = (float)Wl * pw;
-          gl_p[2 * (l * 4 + k) + 1] = (float)Hl * ph;
-        }
+        pa = half_sum(pa);
+        pw = half_sum(pw);
+        ph = half_sum(ph);
       }
-    };
-    {
-      using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-      using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-      Lv A, B;
-#if MSDA_BWD_DEC_DEPTH == 2
-      issue(I0{}, A); issue(I1{}, B); consume(I0{}, A);
-      issue(I2{}, A); consume(I1{}, B);
-      issue(I3{}, B); consume(I2{}, A);
-      consume(I3{}, B);
-#else
-      issue(I0{}, A); consume(I0{}, A); issue(I1{}, A); consume(I1{}, A);
-      issue(I2{}, A); consume(I2{}, A); issue(I3{}, A); consume(I3{}, A);
-      (void)B;
-#endif
+      if (live && lane == 0) {
+        ga_p[k] = pa;
+        gl_p[2 * k] = (float)Wl * pw;
+        gl_p[2 * k + 1] = (float)Hl * ph;
+      }
     }
   }
   __syncthreads();

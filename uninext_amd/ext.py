@@ -41,9 +41,9 @@ _geometry_checks = CheckedOnce()
 @contextlib.contextmanager
 def call_site(site):
     """Forward calls made inside the block belong to call site `site` (0..63): the library chooses between its two
-    encoder-forward kernels PER SITE.  MSDeformAttn modules wrap their operator calls in their own; the bare operator
-    uses site 0."""
-    prev = getattr(_site, "value", 0)
+    encoder-forward kernels PER SITE.  MSDeformAttn modules wrap their operator calls in their own.  Outside of any block
+    the site is derived from the call sequence (`_auto_site`)."""
+    prev = getattr(_site, "value", None)
     _site.value = int(site)
     try:
         yield
@@ -52,9 +52,90 @@ def call_site(site):
 
 
 def current_call_site():
-    """The call site of the enclosing call_site() block (0 outside of one) -- autograd functions record it in forward and
-    re-enter it in backward, which runs on another thread."""
-    return int(getattr(_site, "value", 0))
+    """The call site of the enclosing call_site() block (0 outside of one)."""
+    v = getattr(_site, "value", None)
+    return 0 if v is None else int(v)
+
+
+def explicit_call_site():
+    """The call site of the enclosing call_site() block, None outside of one -- autograd functions record it in forward
+    and re-enter it in backward, which runs on another thread (`reenter`)."""
+    v = getattr(_site, "value", None)
+    return None if v is None else int(v)
+
+
+def reenter(site):
+    """Context manager for a backward: the forward's explicit call site again, or nothing when it had none (the call is
+    then matched to its forward by the derived-site rules below)."""
+    return call_site(site) if site is not None else contextlib.nullcontext()
+
+
+# ---- call sites for callers that pass none: the reference's UNMODIFIED module on top (INTEGRATION.md option A) --------------
+# ops/modules/ms_deform_attn.py:113 calls MSDeformAttnFunction.apply with no notion of a call site, from six encoder layers
+# (dino.py:338,363) that sample differently.  Deformable-DETR builds `spatial_shapes` once per forward pass of the transformer
+# and hands the SAME tensor object to every layer, so the ordinal of an encoder-shaped call since that object was first seen
+# is the layer index: site = AUTO_SITE_BASE + ordinal % AUTO_SITES.  The backward of such a call arrives on the autograd
+# thread with the forward's saved tensors: it is matched to its forward by the storage of `sampling_loc` (a tensor the
+# layer made for this call alone and autograd keeps alive until then).  A caller that repeats ONE call in a loop on the same
+# shapes object walks through the 16 derived slots (each settles on its kernel at its third visit): wrap such loops in
+# call_site().  This repository's own modules pass explicit sites 1..63 from a counter of instances; a
+# process that mixes both kinds of module may see two layers share a slot's history, which costs speed, never results.
+AUTO_SITE_BASE, AUTO_SITES = 48, 16
+_AUTO_BWD_KEEP = 256                      # forward calls remembered for their backward (inference never consumes them)
+
+
+class _AutoSites:
+    def __init__(self):
+        self.lock = threading.Lock()
+        self.shapes_ref = None            # weak reference to the spatial_shapes object of the current pass
+        self.shapes_version = -1
+        self.ordinal = 0
+        self.by_loc = {}                  # sampling_loc.data_ptr() -> site, insertion-ordered
+        self.last = -1                    # the site the last context carried (tests, bench)
+
+    def forward(self, spatial_shapes, sampling_loc):
+        import weakref
+        with self.lock:
+            cur = self.shapes_ref() if self.shapes_ref is not None else None
+            if cur is not spatial_shapes or self.shapes_version != spatial_shapes._version:
+                self.shapes_ref = weakref.ref(spatial_shapes)
+                self.shapes_version = spatial_shapes._version
+                self.ordinal = 0
+            site = AUTO_SITE_BASE + self.ordinal % AUTO_SITES
+            self.ordinal += 1
+            if sampling_loc is not None:
+                self.by_loc[int(sampling_loc.data_ptr())] = site
+                while len(self.by_loc) > _AUTO_BWD_KEEP:
+                    self.by_loc.pop(next(iter(self.by_loc)))
+            return site
+
+    def backward(self, sampling_loc):
+        with self.lock:
+            return self.by_loc.pop(int(sampling_loc.data_ptr()), None)
+
+
+_auto = _AutoSites()
+
+
+def reset_auto_sites():
+    """Start a new pass for the derived call sites: the next encoder-shaped call without a call_site() block is layer 0.
+    Only needed by a caller that REUSES one spatial_shapes tensor object across forward passes (the reference rebuilds it)."""
+    with _auto.lock:
+        _auto.shapes_ref, _auto.shapes_version, _auto.ordinal = None, -1, 0
+
+
+def _auto_site(spatial_shapes, sampling_loc, backward=False):
+    """Site of an encoder-shaped call made outside of every call_site() block (see above).  A backward call whose forward is
+    unknown gets -1: no history, the library's history-free kernel."""
+    if backward:
+        site = _auto.backward(sampling_loc)
+        return -1 if site is None else site
+    return _auto.forward(spatial_shapes, sampling_loc)
+
+
+def last_call_site():
+    """The call site the last encoder-shaped call of this process carried (explicit or derived); -1 before the first."""
+    return _auto.last
 
 
 def _geometry_checked(spatial_shapes, level_start_index, spatial_size):
@@ -75,7 +156,7 @@ def _geometry_checked(spatial_shapes, level_start_index, spatial_size):
     return ok
 
 
-def _set_call_context(lib, value_dtype, spatial_shapes, level_start_index, S, M_D, L, Lq, P):
+def _set_call_context(lib, value_dtype, spatial_shapes, level_start_index, S, M_D, L, Lq, P, sampling_loc=None, backward=False):
     """Describe the coming forward or backward call to the library.  Only encoder-shaped fp32 calls have a choice to make; for
     everything else no context is set (and nothing is copied to the host)."""
     if value_dtype != torch.float32 or Lq != S or S < 1024 or L != 4 or P != 4 or M_D != 32:
@@ -83,7 +164,11 @@ def _set_call_context(lib, value_dtype, spatial_shapes, level_start_index, S, M_
     flags = CTX_GEOMETRY_CHECKED if _geometry_checked(spatial_shapes, level_start_index, S) else 0
     if torch.are_deterministic_algorithms_enabled():
         flags |= CTX_DETERMINISTIC
-    lib.msda_hip_set_call_context(int(getattr(_site, "value", 0)), flags)
+    site = getattr(_site, "value", None)
+    if site is None:
+        site = _auto_site(spatial_shapes, sampling_loc, backward)
+    _auto.last = int(site)
+    lib.msda_hip_set_call_context(int(site), flags)
 
 
 def _check(name, t, dev):
@@ -169,7 +254,7 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)  # kernel writes every element
     with torch.cuda.device(value.device):
         stream = torch.cuda.current_stream().cuda_stream
-        _set_call_context(lib, value.dtype, spatial_shapes, level_start_index, S, D, L, Lq, P)
+        _set_call_context(lib, value.dtype, spatial_shapes, level_start_index, S, D, L, Lq, P, sampling_loc)
         rc = getattr(lib, "msda_hip_forward_" + suf)(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
             attn_weight.data_ptr(), N, S, M, D, L, Lq, P, out.data_ptr(), ctypes.c_void_p(stream))
@@ -201,7 +286,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     with torch.cuda.device(value.device):
         stream = torch.cuda.current_stream().cuda_stream
         ws_bytes = int(lib.msda_hip_backward_workspace_bytes(N, S, M, D, L, Lq, P)) if TORCH_WORKSPACE and suf == "f32" else 0
-        _set_call_context(lib, value.dtype, spatial_shapes, level_start_index, S, D, L, Lq, P)
+        _set_call_context(lib, value.dtype, spatial_shapes, level_start_index, S, D, L, Lq, P, sampling_loc, backward=True)
         if ws_bytes > 0:
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=value.device)   # freed (to the cache) in stream order
             rc = lib.msda_hip_backward_ws_f32(

@@ -239,7 +239,7 @@ class MSDeformAttn(CachedModuleMixin, nn.Module):
                   and query.dtype == torch.float32 and not torch.is_autocast_enabled()):
                 # autograd records: the same fused forward, differentiable (training side)
                 sampled = MSDeformAttnFusedFunction.apply(value, input_spatial_shapes, input_level_start_index,
-                                                          reference_points, offsets, logits, self.n_points)
+                                                          reference_points, offsets, logits, self.n_points, self.im2col_step)
             else:
                 sampled = self._sample_autograd(value, input_spatial_shapes, input_level_start_index, reference_points,
                                                 offsets, logits)
