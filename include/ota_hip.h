@@ -10,7 +10,11 @@
  * around the conflict resolution and the repair `while` (:409,:417,:427) -- by two kernels for the whole batch that never
  * return to the host.  The results are INTEGERS (which queries serve which ground truth), so every float that decides one is
  * formed by the reference's float32 operations in the reference's order (no FMA contraction, IEEE division), and every
- * selection uses PyTorch's tie rule (lowest index first):
+ * selection uses PyTorch's tie rule (lowest index first).  The two multi-term reductions -- a target's class cost over its
+ * positive tokens and the sum of its ten largest IoUs -- are SEQUENTIAL sums here (ascending token order / descending IoU);
+ * PyTorch's GPU reduction kernels may associate three or more terms differently, so a cost can differ from the PyTorch
+ * composition's by one unit in the last place (exact against oracle/ota_oracle.py, which is pinned to the reference's
+ * integers on the fixtures):
  *
  *   ota_cost_hip_f32     per (query, target) pair of every image
  *       class = (sum over the target's positive tokens, ascending, of class_table[q, t]) * (1 / count)         (:329-334)
@@ -22,7 +26,9 @@
  *     class_table [batch, Q, T] is the focal table pos - neg of matcher.py:327-330, which the caller forms with the
  *     reference's own elementwise PyTorch operations (bitwise the reference's on the same device -- the device library's
  *     logf and the one PyTorch was built with differ in the last place on a third of the arguments, so the table is not
- *     recomputed here).  Also written: iou and one byte in_box | in_centre per pair (the foreground test of :374).
+ *     recomputed here).  Also written: iou and one byte per pair: bit 0 = in_box | in_centre (the foreground test of :374),
+ *     bit 1 = a box of the pair is degenerate (x1 < x0, y1 < y0 or NaN) -- the reference's generalized_box_iou asserts
+ *     against those (util/box_ops.py:76-77) and aborts the training step.
  *
  *   ota_dynamic_k_hip    one 1024-thread workgroup per image, everything of :340 and :387-447 in order
  *       cost[q, :] += 10000 for queries inside no box and no centre square                                       (:340)
@@ -34,7 +40,9 @@
  *         that mask, :406 vs :432) are reset to their cheapest target                                          (:417-435)
  *       selected queries ascending with the first target of their row; per target the cheapest query among its own (:441-447)
  *     `cost` is modified in place exactly as the reference modifies it.  A repair loop that does not terminate within
- *     `max_rounds` rounds (the reference would spin forever) sets status 2.
+ *     `max_rounds` rounds (the reference would spin forever) sets status 2; an image with a degenerate box (bit 1 of a flag)
+ *     gets status 4 on top (its assignment is computed anyway, NaN costs sorting last: the caller decides -- the Python
+ *     binding raises the reference's AssertionError behind its one host copy).
  *
  * Batch layout: image b has targets gt_off[b] .. gt_off[b + 1] - 1 of the concatenated target arrays; its [Q, G_b] blocks
  * of cost / iou / flags / matching start at element Q * gt_off[b].  All pointers are device memory; kernels are only
@@ -68,7 +76,8 @@ int ota_cost_hip_f32(const float* class_table, const float* boxes, const float* 
  * undefined before, the final 0 / 1 matching matrix after.
  * Outputs per image b (G_b > 0): sel_query[b * Q .. ] int64, ascending, and sel_gt[b * Q ..] int64 -- the first
  * num_selected[b] entries are valid; matched_query int64 [G_total]: per target its cheapest own query; num_selected int32
- * [batch] (0 for an image without targets); status int32 [batch]: 0 ok, 2 repair loop cut off after max_rounds.
+ * [batch] (0 for an image without targets); status int32 [batch]: 0 ok, bit 1 (2) repair loop cut off after max_rounds,
+ * bit 2 (4) a predicted or target box of the image is degenerate.
  */
 int ota_dynamic_k_hip(float* cost, const float* iou, const uint8_t* flags, uint8_t* matching, const int32_t* gt_off,
                       int batch, int num_queries, int max_rounds, int64_t* sel_query, int64_t* sel_gt,

@@ -20,7 +20,8 @@ TOP_IOU = 10                    # matcher.py:391
 
 
 def cost_terms(class_table, boxes, tgt_boxes, positive_map):
-    """-> cost [Q, G] (before the background penalty of :340), iou [Q, G], flags [Q, G] uint8 (in box | in centre)."""
+    """-> cost [Q, G] (before the background penalty of :340), iou [Q, G], flags [Q, G] uint8: bit 0 = in box | in centre,
+    bit 1 = a box of the pair fails generalized_box_iou's assert (util/box_ops.py:76-77: x1 < x0, y1 < y0 or NaN)."""
     table = np.asarray(class_table, F)
     bq, g = np.asarray(boxes, F), np.asarray(tgt_boxes, F)
     pm = np.asarray(positive_map) != 0
@@ -52,20 +53,26 @@ def cost_terms(class_table, boxes, tgt_boxes, positive_map):
     in_ctr = (cx > g[:, 0] - CENTRE_HALF) & (cx < g[:, 0] + CENTRE_HALF) & (cy > g[:, 1] - CENTRE_HALF) & (cy < g[:, 1] + CENTRE_HALF)
     cost = (cls + GIOU_WEIGHT * (-giou)) + PRIOR_PENALTY * np.where(in_box & in_ctr, F(0), F(1))
     assert cost.dtype == F and iou.dtype == F
-    return cost, iou, (in_box | in_ctr).astype(np.uint8)
+    with np.errstate(invalid="ignore"):
+        bad_q, bad_g = ~(bx1 >= bx0) | ~(by1 >= by0), ~(gx1 >= gx0) | ~(gy1 >= gy0)
+    degenerate = bad_q[:, None] | bad_g[None, :]
+    return cost, iou, ((in_box | in_ctr).astype(np.uint8) | (degenerate.astype(np.uint8) << 1))
 
 
 def _first_argmin(v):
-    """Index of the smallest value, lowest index among equals, NaN behind everything."""
-    return int(np.argmin(np.where(np.isnan(v), np.inf, v)))
+    """torch.min / argmin with indices: the first minimum -- and NaN PROPAGATES: the first NaN is the minimum (top-k, in
+    contrast, sorts NaN behind everything: handled where it is used)."""
+    return int(np.argmin(np.where(np.isnan(v), -np.inf, v)))
 
 
 def dynamic_k(cost, iou, flags, max_rounds=10000):
     """cost [Q, G] float32 (MODIFIED IN PLACE as the reference modifies it), iou, flags as from cost_terms.
-    -> (selected_query int64 ascending, gt_index int64, matched_query int64 [G], matching uint8 [Q, G], status)."""
+    -> (selected_query int64 ascending, gt_index int64, matched_query int64 [G], matching uint8 [Q, G], status: bit 1 (2) =
+    the repair loop was cut off, bit 2 (4) = a degenerate box)."""
     Q, G = cost.shape
     assert cost.dtype == F and G > 0
-    fg = flags.any(1)
+    fg = (flags & 1).any(1)
+    degenerate = 4 if (flags & 2).any() else 0          # the reference asserts and aborts; include/ota_hip.h: status bit 2
     cost[~fg] = cost[~fg] + BG_PENALTY                                                        # :340
     M = np.zeros((Q, G), np.uint8)
     ncand = min(Q, TOP_IOU)
@@ -76,7 +83,7 @@ def dynamic_k(cost, iou, flags, max_rounds=10000):
         for q in order:
             if not np.isnan(col[q]):
                 s = F(s + col[q])                                                             # summed in descending order
-        k = max(int(s), 1)                                                                    # :397
+        k = 1 if np.isnan(col).any() else max(int(s), 1)                                      # :397 (topk ranks NaN largest: NaN sum -> 1)
         c = np.where(np.isnan(cost[:, g]), np.inf, cost[:, g])
         M[np.lexsort((np.arange(Q), c))[:k], g] = 1                                           # :399-402, ties to the lowest index
     claims = M.sum(1)
@@ -105,6 +112,7 @@ def dynamic_k(cost, iou, flags, max_rounds=10000):
     gt = np.array([int(np.argmax(M[q])) for q in sel], np.int64)                              # first maximum (:440)
     matched = np.zeros(G, np.int64)
     for g in range(G):
-        c = np.where(M[:, g] != 0, np.where(np.isnan(cost[:, g]), np.inf, cost[:, g]), np.inf)
-        matched[g] = int(np.argmin(c))                                                        # :445-446
-    return sel, gt, matched, M, status
+        with np.errstate(invalid="ignore"):
+            c = np.where(M[:, g] != 0, cost[:, g], cost[:, g] + F(np.inf))                    # :439 (NaN + inf stays NaN)
+        matched[g] = _first_argmin(c)                                                         # :440
+    return sel, gt, matched, M, status | degenerate

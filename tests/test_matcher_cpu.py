@@ -84,7 +84,7 @@ def test_ota_oracle_is_pinned_to_the_reference_fixtures(name):
         assert np.array_equal(iou, want_iou.numpy())
         # bitwise for targets of one or two tokens; three tokens: PyTorch's CPU mean divides by 3 where its GPU mean (the
         # kernels' and the oracle's rule) multiplies by fl(1 / 3) -- one unit in the last place of a cost near 100
-        full = cost + np.where(flags.any(1), 0, 10000.0).astype(np.float32)[:, None]
+        full = cost + np.where((flags & 1).any(1), 0, 10000.0).astype(np.float32)[:, None]
         ntok = targets[b]["positive_map"].sum(1).numpy()
         assert np.array_equal(full[:, ntok <= 2], want_cost.numpy()[:, ntok <= 2])
         assert float(np.abs(full - want_cost.numpy()).max()) <= 7.63e-6 * max(1.0, float(np.abs(full).max()) / 64.0)
@@ -121,6 +121,67 @@ def test_ota_oracle_equals_the_reference_loop_on_conflict_heavy_inputs(seed):
     assert status == 0
     assert np.array_equal(sel, ref_idx[0].numpy()) and np.array_equal(gt, ref_idx[1].numpy())
     assert np.array_equal(matched, ref_matched.numpy())
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_ota_oracle_follows_pytorch_on_nan_ious_of_zero_area_boxes(seed):
+    """a zero-area query on a zero-area target passes the reference's box assert (x1 >= x0 holds) and has IoU 0 / 0.
+    torch.topk ranks that NaN LARGEST (the column's k becomes int(NaN) clamped to 1), torch.min / argmin PROPAGATE it (the
+    NaN's row is "the cheapest", matched or not): the oracle -- and with it the kernels of include/ota_hip.h -- do the same."""
+    from oracle import ota_oracle
+    g = torch.Generator().manual_seed(600 + seed)
+    Q, T, G = 60, 8, 4 + seed
+    logits = torch.randn(1, Q, T, generator=g)
+    boxes = torch.cat([torch.rand(1, Q, 2, generator=g), 0.05 + 0.3 * torch.rand(1, Q, 2, generator=g)], -1)
+    tb = torch.cat([0.3 + 0.4 * torch.rand(G, 2, generator=g), 0.1 + 0.3 * torch.rand(G, 2, generator=g)], -1)
+    tb[2, 2:] = 0.0
+    boxes[0, 9 + seed] = tb[2]
+    pm = torch.zeros(G, T, dtype=torch.bool)
+    pm[torch.arange(G), torch.arange(G) % T] = True
+    m = HungarianMatcherVL(cost_class=2, cost_bbox=5, cost_giou=2)
+    m.batched_topk = False
+    (ref_idx,), (ref_matched,) = m.forward_ota({"pred_logits": logits, "pred_boxes": boxes}, [{"boxes": tb, "positive_map": pm}])
+    cost, iou, flags = ota_oracle.cost_terms(_focal_table(logits)[0].numpy(), boxes[0].numpy(), tb.numpy(), pm.numpy())
+    assert np.isnan(iou).sum() == 1 and not (flags & 2).any()
+    sel, gt, matched, M, status = ota_oracle.dynamic_k(cost, iou, flags)
+    assert status == 0
+    assert np.array_equal(sel, ref_idx[0].numpy()) and np.array_equal(gt, ref_idx[1].numpy())
+    assert np.array_equal(matched, ref_matched.numpy())
+
+
+def test_ota_oracle_flags_degenerate_boxes_like_the_reference_assert():
+    """the reference's generalized_box_iou asserts `(boxes[:, 2:] >= boxes[:, :2]).all()` on the predicted and
+    on the target boxes (util/box_ops.py:76-77) -- a negative width / height or a NaN aborts the step.  The device path
+    (include/ota_hip.h) reports it as bit 1 of the pair flags and status bit 2 (4) of the image; the oracle mirrors that, and
+    the composition path raises the AssertionError itself."""
+    from oracle import ota_oracle
+    g = torch.Generator().manual_seed(77)
+    Q, T, G = 40, 8, 3
+    logits = torch.randn(1, Q, T, generator=g)
+    boxes = torch.cat([torch.rand(1, Q, 2, generator=g), 0.05 + 0.2 * torch.rand(1, Q, 2, generator=g)], -1)
+    tb = torch.cat([0.3 + 0.4 * torch.rand(G, 2, generator=g), 0.1 + 0.2 * torch.rand(G, 2, generator=g)], -1)
+    pm = torch.zeros(G, T, dtype=torch.bool)
+    pm[torch.arange(G), torch.arange(G)] = True
+    table = _focal_table(logits)[0].numpy()
+    cost, iou, flags = ota_oracle.cost_terms(table, boxes[0].numpy(), tb.numpy(), pm.numpy())
+    assert not (flags & 2).any() and ota_oracle.dynamic_k(cost, iou, flags)[4] == 0
+    for what in ("negative width", "nan", "negative target height"):
+        b2, t2 = boxes.clone(), tb.clone()
+        if what == "negative width":
+            b2[0, 5, 2] = -0.1
+        elif what == "nan":
+            b2[0, 7, 1] = float("nan")
+        else:
+            t2[1, 3] = -0.05
+        cost, iou, flags = ota_oracle.cost_terms(table, b2[0].numpy(), t2.numpy(), pm.numpy())
+        assert (flags & 2).any()
+        if what != "negative target height":
+            row = 5 if what == "negative width" else 7
+            assert (flags[row] & 2).all() and not (np.delete(flags, row, 0) & 2).any()
+        assert ota_oracle.dynamic_k(cost, iou, flags)[4] & 4
+        m = HungarianMatcherVL(cost_class=2, cost_bbox=5, cost_giou=2)
+        with pytest.raises(AssertionError):                       # the composition = the reference's own behaviour
+            m.forward_ota({"pred_logits": logits, "pred_boxes": b2}, [{"boxes": t2, "positive_map": pm}])
 
 
 @pytest.mark.parametrize("seed", range(8))

@@ -166,6 +166,68 @@ def test_ota_device_on_conflict_heavy_batches(seed):
             assert np.array_equal(dev_matched[b].cpu().numpy(), loop_matched[b].cpu().numpy())
 
 
+def test_ota_device_follows_pytorch_on_nan_ious_of_zero_area_boxes():
+    """tests/test_matcher_cpu.py::test_ota_oracle_follows_pytorch_on_nan_ious_of_zero_area_boxes, on the device: k = 1 for a
+    column with a NaN IoU, the NaN's row wins every min / argmin."""
+    from oracle import ota_oracle
+    from uninext_amd.matcher import FOCAL_ALPHA, FOCAL_GAMMA
+    for seed in range(4):
+        g = torch.Generator().manual_seed(600 + seed)
+        Q, T, G = 60, 8, 4 + seed
+        logits = torch.randn(1, Q, T, generator=g)
+        boxes = torch.cat([torch.rand(1, Q, 2, generator=g), 0.05 + 0.3 * torch.rand(1, Q, 2, generator=g)], -1)
+        tb = torch.cat([0.3 + 0.4 * torch.rand(G, 2, generator=g), 0.1 + 0.3 * torch.rand(G, 2, generator=g)], -1)
+        tb[2, 2:] = 0.0
+        boxes[0, 9 + seed] = tb[2]
+        pm = torch.zeros(G, T, dtype=torch.bool)
+        pm[torch.arange(G), torch.arange(G) % T] = True
+        m = HungarianMatcherVL(cost_class=2, cost_bbox=5, cost_giou=2)
+        outputs = {"pred_logits": logits.cuda(), "pred_boxes": boxes.cuda()}
+        (idx,), (matched,) = m.forward_ota(outputs, [{"boxes": tb.cuda(), "positive_map": pm.cuda()}])
+        prob = outputs["pred_logits"].sigmoid()
+        table = (FOCAL_ALPHA * ((1 - prob) ** FOCAL_GAMMA) * (-(prob + 1e-8).log())
+                 - (1 - FOCAL_ALPHA) * (prob ** FOCAL_GAMMA) * (-(1 - prob + 1e-8).log())).cpu().numpy()
+        cost, iou, flags = ota_oracle.cost_terms(table[0], boxes[0].numpy(), tb.numpy(), pm.numpy())
+        assert np.isnan(iou).sum() == 1
+        sel, gt, o_matched, M, st = ota_oracle.dynamic_k(cost, iou, flags)
+        assert np.array_equal(idx[0].cpu().numpy(), sel) and np.array_equal(idx[1].cpu().numpy(), gt)
+        assert np.array_equal(matched.cpu().numpy(), o_matched)
+
+
+@pytest.mark.parametrize("what", ["negative width", "nan", "negative target height"])
+def test_ota_device_raises_the_reference_assert_on_degenerate_boxes(what):
+    """the device simOTA path used to map NaN costs to +inf and return an assignment where the reference's
+    generalized_box_iou aborts the step (util/box_ops.py:76-77).  ota_cost_hip_f32 now marks such pairs, ota_dynamic_k_hip turns
+    the mark into status 4 of the image, and the binding raises AssertionError behind its ONE host copy (no extra sync)."""
+    g = torch.Generator().manual_seed(78)
+    bs, Q, T, G = 2, 300, 16, 5
+    logits = torch.randn(bs, Q, T, generator=g)
+    boxes = torch.cat([torch.rand(bs, Q, 2, generator=g), 0.05 + 0.2 * torch.rand(bs, Q, 2, generator=g)], -1)
+    targets = []
+    for b in range(bs):
+        tb = torch.cat([0.3 + 0.4 * torch.rand(G, 2, generator=g), 0.1 + 0.2 * torch.rand(G, 2, generator=g)], -1)
+        pm = torch.zeros(G, T, dtype=torch.bool)
+        pm[torch.arange(G), torch.arange(G)] = True
+        targets.append({"boxes": tb.cuda(), "positive_map": pm.cuda()})
+    m = HungarianMatcherVL(cost_class=2, cost_bbox=5, cost_giou=2)
+    assert m.device_ota
+    m.forward_ota({"pred_logits": logits.cuda(), "pred_boxes": boxes.cuda()}, targets)          # clean inputs: fine
+    if what == "negative width":
+        boxes[1, 17, 2] = -0.1
+    elif what == "nan":
+        boxes[0, 3, 0] = float("nan")
+    else:
+        targets[1]["boxes"][2, 3] = -0.05
+    outputs = {"pred_logits": logits.cuda(), "pred_boxes": boxes.cuda()}
+    *_, status, _sizes = m.ota_device_launch(outputs["pred_logits"].sigmoid(), outputs["pred_boxes"], targets)
+    assert status.tolist() == ([4, 0] if what == "nan" else [0, 4])
+    with pytest.raises(AssertionError, match="degenerate box"):
+        m.forward_ota(outputs, targets)
+    m.device_ota = False
+    with pytest.raises(AssertionError):                               # the composition: the reference's own assert
+        m.forward_ota(outputs, targets)
+
+
 def _ulps(a, b):
     """Distance in float32 units in the last place (same-sign finite values)."""
     ia, ib = a.view(torch.int32).to(torch.int64), b.view(torch.int32).to(torch.int64)

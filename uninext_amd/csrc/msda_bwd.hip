@@ -413,8 +413,7 @@ int launch_backward<float>(int variant, const float* grad_out, const float* valu
   }
   if (variant == kBwdDec) variant = kGeneric;
   if (variant == kBwdRegions && regions_backward_ok(d)) {
-    *kernel_name = "msda_bwd_regions";
-    return launch_backward_regions(grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, stream);
+    return launch_backward_regions(grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, stream, kernel_name);
   }
   if (variant == kBwdRegions) variant = tl ? kTiled : kGeneric;
   constexpr int kBwdWin2 = 7;           // backward variant 7: msda_bwd_win2 (one window set, two workgroups per CU; experiments/)

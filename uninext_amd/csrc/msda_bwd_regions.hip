@@ -19,8 +19,9 @@
 //               concerns grad_value compiled out (msda_bwd_tiled_nogv).
 //   regions   = msda_bwd_regions_add: a workgroup per bin reads the bin's records in order, a half wave per record (lane =
 //               channel: one coalesced 128-byte row of grad_output), adds the corners that lie INSIDE the region into a
-//               float64 LDS tile (ds_add_f64 is native on gfx950, no fixed-point scale, no bound to respect) and STORES the
-//               tile: every pixel of grad_value is written exactly once, by its owner -- no global atomic, no memset.
+//               float64 LDS tile (ds_add_f64 is native on gfx950, no fixed-point scale, no bound to respect) and ADDS the
+//               tile to grad_value with a plain read-modify-write: every pixel is touched exactly once, by its owner -- no
+//               global atomic (the C ABI accumulates into grad_value: include/msda_hip.h).
 //
 // The result does not depend on where samples fall, only the record count does.  tools/proto/owner_computes_ref.py is the
 // numpy restatement the filing rule was checked with.
@@ -289,7 +290,9 @@ msda_bwd_regions_add(const float* __restrict__ grad_out, const int64_t* __restri
     for (int p = hw; p < npx; p += kAddHalfWaves) {
       const int cy = y_lo + (p >> cs), cx = x_lo + (p & ((1 << cs) - 1));
       const int64_t pix = lvl_first + (int64_t)cy * W + cx;
-      if (cy < H && cx < W && pix < d.S) gv_head[pix * d.M * 32] = (float)tile[p * 32 + c];
+      // (+=: the C ABI ACCUMULATES into grad_value, include/msda_hip.h, as every other kernel here and the reference's atomics do;
+      // this workgroup owns the pixel, so a plain read-modify-write is the accumulation)
+      if (cy < H && cx < W && pix < d.S) gv_head[pix * d.M * 32] += (float)tile[p * 32 + c];
     }
     __syncthreads();                                           // the tile is zeroed for the next bin
   }
@@ -333,7 +336,14 @@ bool regions_backward_ok(const Dims& d) {
 
 int launch_backward_regions(const float* grad_out, const float* value, const int64_t* shapes, const int64_t* lsi,
                             const float* loc, const float* attn, const Dims& d, float* grad_value, float* grad_loc,
-                            float* grad_attn, hipStream_t stream) {
+                            float* grad_attn, hipStream_t stream, const char** kernel_name) {
+  // *kernel_name: the kernel that actually ran -- msda_bwd_tiled when no workspace could be had (stream capture, allocation
+  // failure): the caller's diagnostic must not say msda_bwd_regions then
+  auto tiled_instead = [&]() {
+    if (kernel_name) *kernel_name = "msda_bwd_tiled";
+    return launch_backward_tiled(grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, stream);
+  };
+  if (kernel_name) *kernel_name = "msda_bwd_regions";
   static const int hist_cap = [] {   // tests of the path without the LDS table
     const char* e = std::getenv("MSDA_BWD_REGIONS_HIST");
     const int v = e ? std::atoi(e) : kHistCap;
@@ -352,7 +362,7 @@ int launch_backward_regions(const float* grad_out, const float* value, const int
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cap) != hipSuccess) (void)hipGetLastError();
     if (cap != hipStreamCaptureStatusNone)   // no allocation and no cross-stream hand-over inside a capture
-      return launch_backward_tiled(grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, stream);
+      return tiled_instead();
   }
   Workspace& ws = g_ws[dev];
   std::unique_lock<std::mutex> lock(ws.mu, std::defer_lock);
@@ -376,7 +386,14 @@ int launch_backward_regions(const float* grad_out, const float* value, const int
         ws.buf = nullptr;
         ws.bytes = ws.table_bytes = 0;
       }
-      if (hipError_t e = hipMalloc(reinterpret_cast<void**>(&ws.buf), 3 * ntb + rb); e != hipSuccess) return (int)e;
+      if (hipMalloc(reinterpret_cast<void**>(&ws.buf), 3 * ntb + rb) != hipSuccess) {
+        // ~0.7 GB outside the caller's allocator: when the device cannot spare it the step must not die of a bare hip error
+        // code mid-training -- the query-centric kernel needs no workspace (slower on these patterns, same result)
+        (void)hipGetLastError();
+        ws.buf = nullptr;
+        lock.unlock();
+        return tiled_instead();
+      }
       ws.bytes = 3 * ntb + rb;
       ws.table_bytes = ntb;
       ws.used = false;

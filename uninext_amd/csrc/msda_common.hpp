@@ -129,7 +129,7 @@ size_t regions_workspace_bytes(const Dims& d);              // include/msda_hip.
 void set_call_workspace(void* p, size_t bytes);              // lent to the next backward call of this thread (nullptr: none)
 int launch_backward_regions(const float* grad_out, const float* value, const int64_t* shapes, const int64_t* lsi,
                             const float* loc, const float* attn, const Dims& d, float* grad_value, float* grad_loc,
-                            float* grad_attn, hipStream_t stream);
+                            float* grad_attn, hipStream_t stream, const char** kernel_name = nullptr);
 
 // msda_bwd_win.hip: encoder backward with value AND gradient windows in LDS (fp32, D = 32, L = P = 4, Lq == S).
 bool win_backward_ok(const Dims& d);

@@ -82,7 +82,10 @@ ota_cost_kernel(const float* __restrict__ table, const float* __restrict__ boxes
   const int64_t o = (int64_t)Q * g0 + i;
   cost[o] = (cls + kGiouWeight * (-giou)) + kPriorPenalty * ((in_box && in_ctr) ? 0.0f : 1.0f);
   iou_out[o] = iou;
-  flags[o] = (uint8_t)((in_box || in_ctr) ? 1 : 0);
+  // bit 1: a box of the pair fails the reference's `(boxes[:, 2:] >= boxes[:, :2]).all()` (util/box_ops.py:76-77; NaN fails it too):
+  // the reference aborts the step with an AssertionError; the assignment kernel turns the bit into status 4 of the image
+  const bool degenerate = !(bx1 >= bx0) || !(by1 >= by0) || !(gx1 >= gx0) || !(gy1 >= gy0);
+  flags[o] = (uint8_t)(((in_box || in_ctr) ? 1 : 0) | (degenerate ? 2 : 0));
 }
 
 // ---- wave-level (value, index) reductions: the smallest / largest value, lowest index among equals ---------------------
@@ -102,8 +105,11 @@ __device__ __forceinline__ void wave_argmax(float& v, int& i) {
     if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
   }
 }
-// NaN sorts behind everything, as in PyTorch's top-k
+// NaN costs (0 / 0 IoU of two zero-area boxes).  PyTorch's top-k sorts NaN behind everything (nan_to_inf); its min / argmin
+// PROPAGATE NaN -- the first NaN of a row or column is "the minimum" (nan_first; a real -inf beside a NaN ties with it here and
+// the lower index wins: the one place this file does not follow PyTorch, on inputs no detector produces).
 __device__ __forceinline__ float nan_to_inf(float v) { return v != v ? INFINITY : v; }
+__device__ __forceinline__ float nan_first(float v) { return v != v ? -INFINITY : v; }
 
 constexpr int kOT = 1024, kOW = kOT / 64;
 constexpr int kMaxGt = 4096;                    // targets of one image (unmatched flags live in LDS)
@@ -131,10 +137,10 @@ ota_dynamic_k_kernel(float* __restrict__ cost, const float* __restrict__ iou, co
 
   // a row's cheapest target (torch.min(cost[rows], dim=1): first minimum) replaces everything the row holds
   auto keep_cheapest = [&](int q) {
-    float best = nan_to_inf(C[(int64_t)q * G]);
+    float best = nan_first(C[(int64_t)q * G]);
     int arg = 0;
     for (int g = 1; g < G; ++g) {
-      const float v = nan_to_inf(C[(int64_t)q * G + g]);
+      const float v = nan_first(C[(int64_t)q * G + g]);
       if (v < best) { best = v; arg = g; }
     }
     const uint8_t stale = M[(int64_t)q * G] & kStale;
@@ -149,15 +155,20 @@ ota_dynamic_k_kernel(float* __restrict__ cost, const float* __restrict__ iou, co
   };
 
   // ---- (1) background penalty (matcher.py:340; fg_mask of :374: inside ANY box or ANY centre square), matching = 0 ------
+  int bad = 0;
   for (int q = tid; q < Q; q += kOT) {
     bool fg = false;
-    for (int g = 0; g < G; ++g) fg = fg || F[(int64_t)q * G + g] != 0;
+    for (int g = 0; g < G; ++g) {
+      const uint8_t f = F[(int64_t)q * G + g];
+      fg = fg || (f & 1) != 0;
+      bad |= f & 2;
+    }
     for (int g = 0; g < G; ++g) {
       if (!fg) C[(int64_t)q * G + g] = C[(int64_t)q * G + g] + kBgPenalty;
       M[(int64_t)q * G + g] = 0;
     }
   }
-  __syncthreads();
+  const int degenerate = __syncthreads_or(bad) ? 4 : 0;      // (also the barrier behind this phase)
 
   // ---- (2) dynamic k per target and its k cheapest queries (matcher.py:390-402) -------------------------------------------
   const int ncand = min(Q, kTopIou);
@@ -165,12 +176,13 @@ ota_dynamic_k_kernel(float* __restrict__ cost, const float* __restrict__ iou, co
     // the ncand largest IoUs of the column, in descending order; their sum in that order
     float prev_v = INFINITY, sum = 0.0f;
     int prev_i = -1;
+    bool has_nan = false;
     for (int r = 0; r < ncand; ++r) {
       float bv = -INFINITY;
       int bi = 0x7fffffff;
       for (int q = lane; q < Q; q += 64) {
         const float v = I[(int64_t)q * G + g];
-        if (!(v == v)) continue;                               // (NaN IoU of a degenerate pair: never among the largest here)
+        if (!(v == v)) { has_nan = true; continue; }           // (0 / 0 of two zero-area boxes; see k below)
         const bool after = v < prev_v || (v == prev_v && q > prev_i);
         if (after && (v > bv || (v == bv && q < bi))) { bv = v; bi = q; }
       }
@@ -179,7 +191,9 @@ ota_dynamic_k_kernel(float* __restrict__ cost, const float* __restrict__ iou, co
       sum = sum + bv;
       prev_v = bv; prev_i = bi;
     }
-    const int k = max((int)sum, 1);                             // torch.clamp(topk_ious.sum(0).int(), min=1)
+    // torch.clamp(topk_ious.sum(0).int(), min=1).  torch.topk ranks NaN LARGEST: a column with a NaN IoU has it among its ten,
+    // the sum is NaN, .int() of NaN is 0 (GPU) or INT_MIN (CPU), the clamp makes it 1
+    const int k = __any(has_nan) ? 1 : max((int)sum, 1);
     // the k cheapest queries of the column claim the target (torch.topk(cost[:, g], k, largest=False))
     float pv = -INFINITY;
     int pi = -1;
@@ -235,7 +249,7 @@ ota_dynamic_k_kernel(float* __restrict__ cost, const float* __restrict__ iou, co
       float bv = INFINITY;
       int bi = 0x7fffffff;
       for (int q = lane; q < Q; q += 64) {
-        const float v = nan_to_inf(C[(int64_t)q * G + g]);
+        const float v = nan_first(C[(int64_t)q * G + g]);
         if (v < bv || (v == bv && q < bi)) { bv = v; bi = q; }
       }
       wave_argmin(bv, bi);
@@ -284,14 +298,15 @@ ota_dynamic_k_kernel(float* __restrict__ cost, const float* __restrict__ iou, co
     float bv = INFINITY;
     int bi = 0x7fffffff;
     for (int q = lane; q < Q; q += 64) {
-      if (!(M[(int64_t)q * G + g] & kMatch)) continue;
-      const float v = nan_to_inf(C[(int64_t)q * G + g]);
+      // (an entry outside the matching is cost + inf: +inf -- or NaN, which torch.min then returns even though it is not matched)
+      const float c = C[(int64_t)q * G + g];
+      const float v = nan_first((M[(int64_t)q * G + g] & kMatch) ? c : c + INFINITY);
       if (v < bv || (v == bv && q < bi)) { bv = v; bi = q; }
     }
     wave_argmin(bv, bi);
     if (lane == 0) matched_query[g0 + g] = bi == 0x7fffffff ? 0 : bi;   // (a column of +inf only: torch's argmin of all-inf is 0)
   }
-  if (tid == 0) { num_selected[b] = base; status[b] = st; }
+  if (tid == 0) { num_selected[b] = base; status[b] = st | degenerate; }
 }
 
 }  // namespace

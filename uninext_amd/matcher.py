@@ -20,8 +20,12 @@ where the reference runs it (matcher.py:499-502).
 
 simOTA (`forward_ota`, the matcher of every decoder layer in the shipped configs): for GPU fp32 inputs (`device_ota =
 True`, the default) the whole batch is assigned by two HIP kernels (include/ota_hip.h, csrc/ota.hip) that follow
-matcher.py:313-447 float operation for float operation and tie rule for tie rule; the focal table `pos - neg` that feeds
-them is formed by the reference's own elementwise PyTorch operations.  Nothing synchronises with the host until the
+matcher.py:313-447 operation for operation and tie rule for tie rule: EXACTLY the float32 numpy restatement oracle/ota_oracle.py
+(which returns the reference's integers on every reference-minted fixture), and PyTorch's composition to within one unit in the
+last place of a cost where PyTorch's own GPU reductions (`mean(-1)` over three or more tokens, `sum(0)` over the ten IoUs)
+add in another order than the sequential one used here -- enough to flip a selection only between candidates whose costs are
+that close.  The focal table `pos - neg` that feeds them is formed by the reference's own elementwise PyTorch operations.
+Degenerate boxes (x1 < x0, y1 < y0, NaN) raise the reference's AssertionError behind the one host copy.  Nothing synchronises with the host until the
 selected-query counts are copied back, once per call, to cut the index tensors to their lengths
 (tests/test_matcher_gpu.py asserts that with torch.cuda.set_sync_debug_mode).  CPU inputs and `device_ota = False` run
 the PyTorch composition below -- the reference's data flow with its per-target loops.
@@ -201,7 +205,12 @@ class HungarianMatcherVL(nn.Module):
         sel_q, sel_g, matched, count, status, sizes = self.ota_device_launch(prob, boxes, targets, nf)
         host = torch.stack((count, status)).cpu()                   # THE host synchronisation of the call
         counts, stats = host[0].tolist(), host[1].tolist()
-        if any(s != 0 for s in stats):
+        if any(s & 4 for s in stats):
+            # the reference's generalized_box_iou asserts `(boxes[:, 2:] >= boxes[:, :2]).all()` on both box sets
+            # (util/box_ops.py:76-77; NaN fails it) and aborts the step: same exception, raised behind the one host copy
+            raise AssertionError("simOTA: degenerate box (x1 < x0, y1 < y0 or NaN) in image(s) %s"
+                                 % [b for b, s in enumerate(stats) if s & 4])
+        if any(s & 2 for s in stats):
             raise RuntimeError("simOTA: the repair loop of matcher.py:417-435 did not terminate (the reference would spin)")
         indices, matched_ids, off = [], [], 0
         for b, n in enumerate(sizes):
