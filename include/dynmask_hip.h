@@ -18,6 +18,8 @@
 #ifndef DYNMASK_HIP_H_
 #define DYNMASK_HIP_H_
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -52,6 +54,33 @@ const char* dynmask_hip_last_kernel(void);
  * aligned_bilinear (ddetrs_dn.py:1174-1196): in [n, h, w] -> out [n, factor*h, factor*w]; factor >= 1.
  */
 int aligned_bilinear_hip_f32(const float* in, int n, int h, int w, int factor, float* out, void* stream);
+
+/*
+ * Backward of dynmask_hip_forward_f32 (training: BASELINE configs[4] trains the CondInst head, ddetrs_dn.py:493-560 calls
+ * dynamic_mask_with_coords under autograd).  Same inputs as the forward plus
+ *   grad_logits  [n_inst_all, H, W]     gradient of the loss with respect to out_logits
+ * and the gradients, every element written (no accumulation, no float atomics: results are bitwise repeatable):
+ *   grad_feats   [batch, 8, H, W]       sum over the image's instances (zeros for an image without instances)
+ *   grad_params  [n_inst_all, 169|153]  sum over the pixels, in the layout of `params`
+ *   grad_xy      [n_inst_all, 2] or NULL  gradient with respect to inst_xy (zeros with rel_coord == 0)
+ * workspace: device memory of at least dynmask_hip_backward_workspace_bytes(n_inst_all, H, W) bytes (partial sums of the
+ * pixel slices, dynmask_hip_backward_parts of them per instance), contents undefined before and after; borrowed for the call
+ * in stream order.  At most DYNMASK_HIP_BWD_MAX_BATCH images per call (DYNMASK_ERR_UNSUPPORTED beyond).
+ * The activations are recomputed per (instance, pixel) from the inputs: nothing of the forward has to be kept.
+ */
+#define DYNMASK_HIP_BWD_MAX_BATCH 64
+size_t dynmask_hip_backward_workspace_bytes(int n_inst_all, int H, int W);
+int dynmask_hip_backward_parts(int n_inst_all, int H, int W);
+int dynmask_hip_backward_f32(const float* mask_feats, const float* inst_xy, const float* params, const int* num_insts,
+                             int batch, int channels, int H, int W, int stride, int rel_coord, const float* grad_logits,
+                             float* grad_feats, float* grad_params, float* grad_xy, void* workspace, size_t workspace_bytes,
+                             void* stream);
+
+/*
+ * Backward of aligned_bilinear_hip_f32: grad_out [n, factor*h, factor*w] -> grad_in [n, h, w], every element written; a
+ * gather (each input pixel sums the output pixels that read it, in a fixed order): bitwise repeatable.
+ */
+int aligned_bilinear_hip_backward_f32(const float* grad_out, int n, int h, int w, int factor, float* grad_in, void* stream);
 
 #ifdef __cplusplus
 }

@@ -18,7 +18,13 @@ def golden_names():
 
 def dynmask_names():
     """Dynamic mask head fixtures (tests/golden/make_dynmask_golden.py), without the aligned_bilinear one."""
-    return [n for n in _names() if n.startswith("dynmask_") and n != "dynmask_aligned_bilinear"]
+    return [n for n in _names() if n.startswith("dynmask_") and not n.startswith("dynmask_bwd_") and n != "dynmask_aligned_bilinear"]
+
+
+def dynmask_bwd_names():
+    """Gradient fixtures of the dynamic mask head (tests/golden/make_dynmask_bwd_golden.py: the reference under autograd, float64),
+    without the aligned_bilinear one."""
+    return [n for n in _names() if n.startswith("dynmask_bwd_") and n != "dynmask_bwd_aligned_bilinear"]
 
 
 def patch_names():

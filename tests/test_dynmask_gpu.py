@@ -90,3 +90,94 @@ def test_unsupported_geometry_falls_back_to_torch():
     assert out.shape == (1, 3, 12, 14) and torch.isfinite(out).all()
     with pytest.raises(RuntimeError, match="8 mask-feature channels|inconsistent"):
         ext.dynmask_forward(feats, ref.reshape(-1, 2), params.flatten(0, 1), [3], 8)
+
+
+# ---- the head under autograd (round 5; include/dynmask_hip.h: dynmask_hip_backward_f32, aligned_bilinear_hip_backward_f32) -----
+def _hip_grads(g, up_key="upstream"):
+    t = lambda k: torch.from_numpy(g[k]).float().to(DEV)
+    feats, ref, params = (t(k).requires_grad_(True) for k in ("mask_feats", "reference_points", "mask_head_params"))
+    out = mask_head.dynamic_mask_with_coords(feats, ref, params, g["num_insts"].tolist(), 8, rel_coord=bool(g["rel_coord"]),
+                                             mask_out_stride=int(g["mask_out_stride"]))
+    gf, gr, gp = torch.autograd.grad((out * t(up_key)).sum(), (feats, ref, params), allow_unused=True)
+    return out, gf, (gr if gr is not None else torch.zeros_like(ref)), gp
+
+
+@pytest.mark.parametrize("name", __import__("golden_util").dynmask_bwd_names())
+def test_hip_gradients_match_the_reference_under_autograd(name):
+    """DynMaskFunction + AlignedBilinearFunction against the gradients the reference's own code produced under autograd in
+    float64: within float32 accumulation error, relative to the largest gradient of each tensor; bitwise repeatable."""
+    from golden_util import load_golden
+    g = load_golden(name)
+    out, gf, gr, gp = _hip_grads(g)
+    assert out.grad_fn is not None and type(out.grad_fn).__name__ != "CatBackward0"
+    assert float(np.abs(out.detach().cpu().numpy() - g["out"]).max()) < 1e-5 * max(1.0, float(np.abs(g["out"]).max()))
+    for got, key in ((gf, "grad_mask_feats"), (gr, "grad_reference_points"), (gp, "grad_mask_head_params")):
+        want = g[key]
+        assert tuple(got.shape) == want.shape
+        err = float(np.abs(got.cpu().numpy() - want).max())
+        print("%s %s: max |err| %.2e of max |grad| %.2e" % (name, key, err, float(np.abs(want).max())))
+        assert err < 2e-5 * max(1.0, float(np.abs(want).max())), key
+    _, gf2, gr2, gp2 = _hip_grads(g)
+    assert torch.equal(gf, gf2) and torch.equal(gr, gr2) and torch.equal(gp, gp2)        # no float atomics anywhere
+
+
+@pytest.mark.parametrize("factor", [2, 3, 4])
+def test_hip_aligned_bilinear_gradient(factor):
+    from golden_util import load_golden
+    g = load_golden("dynmask_bwd_aligned_bilinear")
+    x = torch.from_numpy(g["x"]).to(DEV).requires_grad_(True)
+    y = mask_head.aligned_bilinear(x, factor)
+    assert type(y.grad_fn).__name__.startswith("AlignedBilinearFunction")
+    (gx,) = torch.autograd.grad((y * torch.from_numpy(g[f"up{factor}"]).to(DEV)).sum(), (x,))
+    assert np.allclose(gx.cpu().numpy(), g[f"g{factor}"], atol=2e-6)
+
+
+def test_hip_gradients_at_the_training_shape_vs_the_composition():
+    """BASELINE configs[4]: bs 2 padded to 800 x 1344 (mask features 100 x 168), 7 + 19 matched instances, x2 up-sampling: the
+    HIP Functions against the PyTorch composition's autograd (same float32 data flow), with time and peak memory of both."""
+    import time
+    g = torch.Generator().manual_seed(31)
+    N, H, W, counts = 2, 100, 168, [7, 19]
+    n_all = sum(counts)
+    feats = torch.randn(N, 8, H, W, generator=g).to(DEV)
+    ref = (torch.rand(1, n_all, 2, generator=g) * torch.tensor([W * 8.0, H * 8.0])).to(DEV)
+    params = (torch.randn(1, n_all, 169, generator=g) * 0.3).to(DEV)
+    up = torch.randn(1, n_all, 2 * H, 2 * W, generator=g).to(DEV)
+
+    def run(hip):
+        f, r, p = (t.clone().requires_grad_(True) for t in (feats, ref, params))
+        if hip:
+            out = mask_head.dynamic_mask_with_coords(f, r, p, counts, 8)
+        else:
+            logits = mask_head._dynamic_convs_torch(f, r.reshape(-1, 2), p.flatten(0, 1), counts, 8, True).reshape(-1, 1, H, W)
+            out = mask_head._aligned_bilinear_torch(logits, 2).reshape(1, n_all, 2 * H, 2 * W)
+        return (out,) + torch.autograd.grad((out * up).sum(), (f, r, p))
+
+    res = {}
+    for hip in (True, False):
+        run(hip)
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            o = run(hip)
+        torch.cuda.synchronize()
+        res[hip] = (o, (time.perf_counter() - t0) / 10 * 1e3, (torch.cuda.max_memory_allocated() - base) / 2 ** 20)
+    print("dynamic mask head forward + backward, bs 2, 100 x 168, %d instances: HIP %.3f ms / %.1f MiB peak, PyTorch composition "
+          "%.3f ms / %.1f MiB peak" % (n_all, res[True][1], res[True][2], res[False][1], res[False][2]))
+    for a, b, name in zip(res[True][0], res[False][0], ("out", "grad_feats", "grad_ref", "grad_params")):
+        scale = max(1.0, float(b.abs().max()))
+        assert float((a - b).abs().max()) < 1e-4 * scale, name
+    assert res[True][2] < res[False][2]
+
+
+def test_hip_gradients_with_an_image_without_instances_and_detached_inputs():
+    g = torch.Generator().manual_seed(32)
+    feats = torch.randn(3, 8, 9, 14, generator=g).to(DEV).requires_grad_(True)
+    ref = (torch.rand(1, 5, 2, generator=g) * 60).to(DEV)                          # detached, as ddetrs_dn.py:391 hands them over
+    params = (torch.randn(1, 5, 169, generator=g) * 0.3).to(DEV).requires_grad_(True)
+    out = mask_head.dynamic_mask_with_coords(feats, ref, params, [2, 0, 3], 8)
+    out.square().sum().backward()
+    assert torch.isfinite(feats.grad).all() and float(feats.grad[1].abs().max()) == 0.0 and float(feats.grad[0].abs().max()) > 0
+    assert torch.isfinite(params.grad).all() and ref.grad is None

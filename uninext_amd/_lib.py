@@ -20,7 +20,9 @@ EXPORTS = (
 )
 
 DYNMASK_EXPORTS = ("dynmask_hip_forward_f32", "aligned_bilinear_hip_f32", "dynmask_hip_set_variant",
-                   "dynmask_hip_last_kernel")   # include/dynmask_hip.h
+                   "dynmask_hip_last_kernel", "dynmask_hip_backward_workspace_bytes", "dynmask_hip_backward_parts",
+                   "dynmask_hip_backward_f32", "aligned_bilinear_hip_backward_f32")   # include/dynmask_hip.h
+DYNMASK_BWD_MAX_BATCH = 64
 PATCH_EMBED_EXPORTS = ("patch_embed_hip_f32", "patch_embed_hip_packed_weight_bytes", "patch_embed_hip_pack_weight_f32",
                        "patch_embed_hip_packed_f32")                           # include/patch_embed_hip.h
 LINEAR_EXPORTS = ("linear_hip_packed_weight_bytes", "linear_hip_pack_weight_f32", "linear_hip_packed_f32",
@@ -96,6 +98,11 @@ def load():
     lib.dynmask_hip_forward_f32.restype = i
     lib.aligned_bilinear_hip_f32.argtypes, lib.aligned_bilinear_hip_f32.restype = [p, i, i, i, i, p, p], i
     lib.dynmask_hip_set_variant.argtypes, lib.dynmask_hip_set_variant.restype = [i], i
+    lib.dynmask_hip_backward_workspace_bytes.argtypes, lib.dynmask_hip_backward_workspace_bytes.restype = [i, i, i], ctypes.c_size_t
+    lib.dynmask_hip_backward_parts.argtypes, lib.dynmask_hip_backward_parts.restype = [i, i, i], i
+    lib.dynmask_hip_backward_f32.argtypes = [p, p, p, p, i, i, i, i, i, i, p, p, p, p, p, ctypes.c_size_t, p]
+    lib.dynmask_hip_backward_f32.restype = i
+    lib.aligned_bilinear_hip_backward_f32.argtypes, lib.aligned_bilinear_hip_backward_f32.restype = [p, i, i, i, i, p, p], i
     lib.dynmask_hip_last_kernel.argtypes, lib.dynmask_hip_last_kernel.restype = [], s
     lib.patch_embed_hip_f32.argtypes, lib.patch_embed_hip_f32.restype = [p, p, p, i, i, i, i, i, i, i, p, p], i
     lib.patch_embed_hip_packed_weight_bytes.argtypes = [i, i, i]

@@ -23,8 +23,17 @@
 //                four coalesced corner loads, the sample's three gradients by a wave reduction, one full-line float atomic per
 //                corner.  A tile with non-finite inputs takes this path for every sample (NaN / Inf propagate as with float
 //                atomics).
-//   flush        when the tile is done every touched accumulator pixel inside the image leaves the CU as ONE full-line
-//                float atomic.
+//   item order   a workgroup walks a contiguous run of its head's tiles DOWN a tile column (round 5).  Consecutive windows then
+//                overlap in their rows: 14 window rows for 8 tile rows on level 0 (10 / 4, 8 / 2, 7 / 1 on the others).
+//   flush        DEFERRED and CARRIED (round 5).  The accumulators of item A are not flushed when A is done but in the head of the
+//                next item B, behind B's window DMA (the flush travels while the value windows land): an accumulator pixel
+//                that is also inside B's window of its level (same window column origin, rows shifted by dy) is MOVED up dy
+//                rows in LDS and keeps collecting; only the rows that leave go to grad_value, as ONE full-line float atomic per
+//                touched pixel.  Round 4 flushed every window whole: 592 slots per item for 170 pixels' worth of queries, 250 MB
+//                written per launch for 114 MB of algorithmic output; a carried transition flushes 260.  The fixed-point scale
+//                is shared along such a chain of items: it comes from the SUM of their bounds (carried values are shifted
+//                right when it grows), and the chain is cut -- everything flushed -- when that sum exceeds 8 x the new tile's
+//                own bound (include/msda_hip.h: steps of <= 2^-19 of the largest upstream gradient of the chain's tiles).
 //
 // Per-sample arithmetic (cuh:113-158, refactored as in msda_bwd_tiled): with F / S the first / second pixel of a corner
 // row in this quad's read order and u the bilinear weight of S:
@@ -52,11 +61,14 @@ static_assert(kAccOff % 256 == 0, "slot parity by address bit 7 in both regions"
 struct Meta {
   int sum[4][4];                                                // per level: sum x0, sum y0, count, - (placement)
   int lvl[4][4];                                                // per level: H, W, first pixel, -
-  int org[4][4];                                                // per level: window origin x, y (flush)
   unsigned gmax_bits, amax_bits, pad0, pad1;                    // per tile: max |grad_out|, max_pair sum |attn| (float bits)
-  unsigned slot_tab[kSlots];                                    // (level << 28) | (row << 14) | column of a window slot
-  unsigned off_tab[kSlots];                                     // per item: byte offset of the slot's pixel in grad_value (head 0), ~0: outside
+  // what is still in the accumulator windows: the last item's window origins, scale exponent, chain bound, and whether it used them
+  int org[4][2];
+  int prevE;
+  unsigned cum_bits;
+  int prev_lds, pad2;
 };
+constexpr int kChainHeadroom = 8;                               // a chain of carried items ends when the sum of its bounds exceeds this x the new tile's
 constexpr int kMetaOff = kAccOff + kSlots * 128;
 constexpr int kLdsBytes = kMetaOff + ((sizeof(Meta) + 15) / 16) * 16;
 static_assert(kLdsBytes <= 160 * 1024, "one workgroup per CU");
@@ -68,7 +80,7 @@ __device__ unsigned long long g_bwin_prof[kProfBlocks * kWaves * kProfSlots];
 #define BW_STAMP(i)                                                                                          \
   do {                                                                                                       \
     const unsigned blk_ = blockIdx.y * gridDim.x + blockIdx.x;                                               \
-    if ((threadIdx.x & 63) == 0 && item == kk + K && blk_ < (unsigned)kProfBlocks)                           \
+    if ((threadIdx.x & 63) == 0 && item == first + 1 && blk_ < (unsigned)kProfBlocks)                           \
       g_bwin_prof[(blk_ * kWaves + (threadIdx.x >> 6)) * kProfSlots + (i)] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
 #else
@@ -167,7 +179,10 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
   }
   const int TY = (lvH[0] + kTH - 1) / kTH, TX = (lvW[0] + kTW - 1) / kTW;
   const int ntiles = TY * TX, nitems = d.N * ntiles;
-  if (kk >= nitems) return;
+  // a contiguous run of the head's items per workgroup; items are numbered image by image, tile column by tile column, DOWN the
+  // column (tile row fastest): consecutive items of a run are vertical neighbours except at a column's end
+  const int R = (nitems + K - 1) / K, first = kk * R, end = min(first + R, nitems);
+  if (first >= nitems) return;
 
   // ---- once per workgroup: zero region, level table, slot table ---------------------------------------------------------
   for (int o = tid * 16; o < kZeroBytes; o += kT * 16) *reinterpret_cast<f32x4*>(smem + kZeroOff + o) = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -176,17 +191,9 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
     *reinterpret_cast<int4*>(&mt.lvl[tid][0]) = make_int4(sel4(t0, t1, lvH[0], lvH[1], lvH[2], lvH[3]), sel4(t0, t1, lvW[0], lvW[1], lvW[2], lvW[3]),
                                                           sel4(t0, t1, lvS[0], lvS[1], lvS[2], lvS[3]), 0);
   }
-  if (tid < kSlots) {
-    const int l = (tid >= kBase[1] ? 1 : 0) + (tid >= kBase[2] ? 1 : 0) + (tid >= kBase[3] ? 1 : 0);
-    const int rel = tid - (l == 0 ? kBase[0] : l == 1 ? kBase[1] : l == 2 ? kBase[2] : kBase[3]);
-    const int ww = l == 0 ? kWW[0] : l == 1 ? kWW[1] : l == 2 ? kWW[2] : kWW[3];
-    const int r = rel / ww, c = rel - r * ww;
-    mt.slot_tab[tid] = ((unsigned)l << 28) | ((unsigned)r << 14) | (unsigned)c;
-  }
-  static_assert(kSlots <= kT, "one slot-table entry per thread");
   for (int o = tid * 16; o < kSlots * 128; o += kT * 16) *reinterpret_cast<f32x4*>(smem + kAccOff + o) = f32x4{0.f, 0.f, 0.f, 0.f};
   if (tid >= 640 && tid < 656) (&mt.sum[0][0])[tid - 640] = 0;
-  if (tid == 656) { mt.gmax_bits = 0u; mt.amax_bits = 0u; }   // (pad0: written by the fetch of every item's first pass before it is read)
+  if (tid == 656) { mt.gmax_bits = 0u; mt.amax_bits = 0u; mt.prev_lds = 0; mt.prevE = 0; mt.cum_bits = 0u; }   // (pad0: written by the fetch of every item's first pass before it is read)
 
   const uint32_t pixB = (uint32_t)M * 128u;                // bytes from a pixel of head m to the next one
   const uint32_t hoff = (uint32_t)m * 128u;
@@ -194,11 +201,13 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
   // ---- steps: one (item, pass) each.  The loads of a step are issued at the end of the step before it -- for the first
   // pass of an item that is between barrier #4 and the flush of the item before, so that they travel under the flush -- and
   // the step in front of the first item only fetches.
-  int item = kk - K, pass = 0, npass = 1;
-  bool body = false;
+  int item = first - 1, pass = 0, npass = 1;
+  bool body = false, tail = false;                         // tail: the step behind the last item (it only flushes)
   int ogx[4] = {0, 0, 0, 0}, ogy[4] = {0, 0, 0, 0};         // window origins of the item
-  float scale = 1.f, inv_scale = 1.f;                      // fixed-point scale of the item's accumulators
-  bool use_lds = false;
+  float scale = 1.f;                                       // fixed-point scale of the item's accumulators: 2^E
+  bool use_lds = false;                                    // the item accumulates in LDS (finite, <= 256 pairs)
+  // (the previous item's origins, scale exponent and chain bound -- what its accumulators, still in LDS, are addressed and
+  // scaled by -- live in Meta: written behind barrier #3 of an item, read in the head of the next)
   bool live = false;                                       // the fetched step: this quad's (query, head) pair ...
   uint32_t pair = 0;
   v2f lc[4];                                               // ... locations and weights of point k on the four levels
@@ -237,12 +246,10 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
 
 
     if (body) {
-      if (pass == 0) {
-        // ---- barrier #1: everybody has left the previous item (its flush left the accumulator windows all zero) ----------
-        BW_STAMP(0);
-        lds_barrier();
-        BW_STAMP(1);
-      }
+      // (no barrier here: barrier #4 at the end of the previous step is the one everybody left the previous item through; its
+      // accumulators are still in LDS -- see the transition below)
+      BW_STAMP(0);
+      BW_STAMP(1);
 
       auto coord = [&](int l, bool& in) __attribute__((always_inline)) {
         const v2f fWH = {(float)lvW[l], (float)lvH[l]};
@@ -252,7 +259,10 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
       };
 
       BW_STAMP(3);                                           // query decoded, loads issued
-      if (pass == 0) {
+      int pgx[4] = {0, 0, 0, 0}, pgy[4] = {0, 0, 0, 0}, prevE = 0, E = 0, carry_mask = 0;   // (pass 0 only)
+      float cum = 0.f;
+      bool prev_lds = false;
+      if (pass == 0 && !tail) {
         // ---- fixed-point scale: every slot receives at most (#pairs of the tile) x max |grad_out| x max_pair sum |attn| ----
         {
           float gm = 0.f;
@@ -296,19 +306,12 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
         BW_STAMP(4);                                         // loads arrived; maxima and placement sums added
         lds_barrier();                                       // #2: sums and scale words complete
         BW_STAMP(5);
-        {
-          const float bound = (float)(kL0Waves * 16 + (int)mt.pad0) * __uint_as_float(mt.gmax_bits) * __uint_as_float(mt.amax_bits);
-          // false for NaN / Inf, and for tiles of more than 256 pairs (pyramids with a finer level after the first): every
-          // sample then takes the float-atomic path (thousands of roundings per pixel at a coarse scale add up past 1e-4)
-          use_lds = bound < 0x1p120f && kL0Waves * 16 + (int)mt.pad0 <= 256;   // (>= 2^120: the clamped exponent below could not scale it into int32)
-          if (use_lds && bound > 0.f) {
-            int e;
-            (void)frexpf(bound, &e);                         // bound < 2^e
-            e = max(-90, min(90, 30 - e));
-            scale = ldexpf(1.f, e);
-            inv_scale = ldexpf(1.f, -e);
-          }
-        }
+        // ---- the item before this one: its origins and scale address what is still in the accumulators ----
+#pragma unroll
+        for (int l = 0; l < 4; ++l) { pgx[l] = mt.org[l][0]; pgy[l] = mt.org[l][1]; }
+        prevE = mt.prevE;
+        prev_lds = mt.prev_lds != 0;
+        cum = __uint_as_float(mt.cum_bits);
         int myOx, myOy;
         {
           const int4 sm = *reinterpret_cast<const int4*>(&mt.sum[k][0]);
@@ -319,12 +322,38 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
           myOy = (int)floorf((float)sm.y * inv + 0.5f) - (myWH - 2) / 2;
           myOx = max(-1, min(myOx, myW + 1 - myWW));
           myOy = max(-1, min(myOy, myH + 1 - myWH));
-          if (tid < 4) *reinterpret_cast<int2*>(&mt.org[k][0]) = make_int2(myOx, myOy);   // for the flush
         }
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
           ogx[l] = __builtin_amdgcn_readlane(myOx, l);
           ogy[l] = __builtin_amdgcn_readlane(myOy, l);
+        }
+        // ---- which levels carry their accumulators over from the previous item, and the scale of this one ----------------------
+        {
+          const int npairs = kL0Waves * 16 + (int)mt.pad0;
+          const float bound = (float)npairs * __uint_as_float(mt.gmax_bits) * __uint_as_float(mt.amax_bits);
+          // false for NaN / Inf, and for tiles of more than 256 pairs (pyramids with a finer level after the first): every
+          // sample then takes the float-atomic path (thousands of roundings per pixel at a coarse scale add up past 1e-4)
+          const bool lds_ok = bound < 0x1p120f && npairs <= 256;   // (>= 2^120: the clamped exponent below could not scale it into int32)
+          int geo = 0;                                            // levels whose window kept its columns and moved down by < its height
+#pragma unroll
+          for (int l = 0; l < 4; ++l)
+            geo |= (ogx[l] == pgx[l] && (unsigned)(ogy[l] - pgy[l]) < (unsigned)kWH[l]) ? (1 << l) : 0;
+          // the chain goes on while its scale stays within kChainHeadroom x of what this tile alone would get (precision) and
+          // this tile's bound is not astronomically larger than the chain's (the carried values are shifted right by < 24 bits)
+          const bool chain = prev_lds && lds_ok && geo != 0 && bound > 0.f && cum <= (float)(kChainHeadroom - 1) * bound &&
+                             bound <= 0x1p20f * cum && cum + bound < 0x1p120f;
+          const float cumB = chain ? cum + bound : bound;
+          int e = 0;
+          if (lds_ok && cumB > 0.f) {
+            (void)frexpf(cumB, &e);                          // cumB < 2^e: what a slot can hold of the chain stays below 2^30
+            e = max(-90, min(90, 30 - e));
+          }
+          carry_mask = chain ? geo : 0;
+          E = e;
+          cum = cumB;
+          use_lds = lds_ok;
+          scale = ldexpf(1.f, E);
         }
         // ---- stage the four value windows: LDS-DMA, one instruction = 8 consecutive slots (1 KB) of ONE level per wave ----
         {
@@ -363,16 +392,61 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
         }
       }
 
-      // where the flush will send each accumulator slot: thread p computes slot p (the windows travel meanwhile)
-      if (tid < kSlots) {
-        const unsigned e = mt.slot_tab[tid];
-        const int l = (int)(e >> 28), r = (int)((e >> 14) & 0x3fffu), c = (int)(e & 0x3fffu);
-        const bool e0 = (l & 1) != 0, e1 = (l & 2) != 0;
-        const int y = sel4(e0, e1, ogy[0], ogy[1], ogy[2], ogy[3]) + r, x = sel4(e0, e1, ogx[0], ogx[1], ogx[2], ogx[3]) + c;
-        const int Hl = sel4(e0, e1, lvH[0], lvH[1], lvH[2], lvH[3]), Wl = sel4(e0, e1, lvW[0], lvW[1], lvW[2], lvW[3]);
-        const int Sl = sel4(e0, e1, lvS[0], lvS[1], lvS[2], lvS[3]);
-        const bool inside = ((unsigned)y < (unsigned)Hl) & ((unsigned)x < (unsigned)Wl);
-        mt.off_tab[tid] = inside ? (uint32_t)(Sl + y * Wl + x) * pixB : 0xffffffffu;
+      if (pass == 0) {
+        if (tail) {                                          // the step behind the last item: everything leaves
+#pragma unroll
+          for (int l = 0; l < 4; ++l) { pgx[l] = mt.org[l][0]; pgy[l] = mt.org[l][1]; }
+          prevE = mt.prevE;
+          prev_lds = mt.prev_lds != 0;
+        }
+        // ---- transition: the previous item's accumulators.  Rows that are also in this item's window move up (and are rescaled
+        // when the chain's scale grew); the rows that leave go to grad_value.  The window DMA issued above travels meanwhile. ----
+        if (prev_lds) {
+          const int ch = tid & 31, hw2 = tid >> 5;             // channel; half wave 0..21
+          const int sh = carry_mask ? prevE - E : 0;           // >= 0: the chain's bound only grows
+          const int rnd = sh > 0 ? 1 << (sh - 1) : 0;
+          const float invA = ldexpf(1.f, -prevE);
+          const int bA = to_sgpr((int)(((float)max(item - 1, 0) + 0.5f) * __builtin_amdgcn_rcpf((float)ntiles)));
+          char* const gvA = reinterpret_cast<char*>(grad_value + (int64_t)bA * d.S * M * 32) + hoff + ch * 4;
+          auto column = [&](auto ltag, int c) __attribute__((always_inline)) {
+            constexpr int LV = decltype(ltag)::value, WH = kWH[LV];
+            constexpr uint32_t kRowB = (uint32_t)kWW[LV] * 128u;
+            const bool carry = ((carry_mask >> LV) & 1) != 0;
+            const int dy = carry ? ogy[LV] - pgy[LV] : WH;      // rows [0, dy) leave, row r + dy becomes row r
+            const uint32_t a0 = smem_base + (uint32_t)kAccOff + (uint32_t)(kBase[LV] + c) * 128u + (uint32_t)ch * 4u;
+            int x[WH], y[WH];
+#pragma unroll
+            for (int r = 0; r < WH; ++r) x[r] = *reinterpret_cast<lds_int_ptr>((uintptr_t)(a0 + (uint32_t)r * kRowB));
+#pragma unroll
+            for (int r = 0; r < WH; ++r)
+              y[r] = r + dy < WH ? *reinterpret_cast<lds_int_ptr>((uintptr_t)(a0 + (uint32_t)(r + dy) * kRowB)) : 0;
+            const int xA = pgx[LV] + c;
+            const bool xin = (unsigned)xA < (unsigned)lvW[LV];
+            const uint32_t col_off = (uint32_t)(lvS[LV] + xA) * pixB;
+#pragma unroll
+            for (int r = 0; r < WH; ++r) {
+              const int yA = pgy[LV] + r;
+              if (r < dy && x[r] != 0 && xin && (unsigned)yA < (unsigned)lvH[LV])
+                atomic_add(reinterpret_cast<float*>(gvA + (size_t)(col_off + (uint32_t)(yA * lvW[LV]) * pixB)), (float)x[r] * invA);
+            }
+#pragma unroll
+            for (int r = 0; r < WH; ++r) {
+              const int nv = (y[r] + rnd) >> sh;
+              if (nv != x[r]) *reinterpret_cast<lds_int_ptr>((uintptr_t)(a0 + (uint32_t)r * kRowB)) = nv;
+            }
+          };
+          using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>;
+          using J2 = std::integral_constant<int, 2>; using J3 = std::integral_constant<int, 3>;
+          column(J0{}, hw2);                                   // 22 half waves = the 22 columns of the level-0 window
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {                        // the 14 + 10 + 8 columns of the other windows
+            const int j = hw2 + t * (kT / 32);
+            if (j < kWW[1]) column(J1{}, j);
+            else if (j < kWW[1] + kWW[2]) column(J2{}, j - kWW[1]);
+            else if (j < kWW[1] + kWW[2] + kWW[3]) column(J3{}, j - kWW[1] - kWW[2]);
+          }
+        }
+        if (tail) break;
       }
       BW_STAMP(6);                                           // origins, window DMA issued
       // ---- sample coordinates; near (all four corners inside the level's window or outside the image) or far? -----------
@@ -399,6 +473,10 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
         // the next item's placement sums and scale words (everybody has read this item's; the next adds come after barrier #1)
         if (tid < 16) (&mt.sum[0][0])[tid] = 0;
         if (tid == 16) { mt.gmax_bits = 0u; mt.amax_bits = 0u; }   // (pad0 is rewritten for every item, before barrier #4 of the one before)
+        // ... and what the NEXT step's transition needs to know about this item's accumulators (everybody has read the previous
+        // item's in front of the transition above)
+        if (tid < 4) { mt.org[tid][0] = sel4(k0, k1, ogx[0], ogx[1], ogx[2], ogx[3]); mt.org[tid][1] = sel4(k0, k1, ogy[0], ogy[1], ogy[2], ogy[3]); }
+        if (tid == 17) { mt.prevE = E; mt.cum_bits = __float_as_uint(cum); mt.prev_lds = use_lds ? 1 : 0; }
       }
 
       if (!l0) __builtin_amdgcn_s_setprio(2);                  // the three youngest waves of the workgroup would finish the pass last
@@ -606,17 +684,17 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
     const bool last = !body || pass + 1 >= npass;
     BW_STAMP(11);
     // ---- the next step: its query, and its loads issued ---------------------------------------------------------------------
-    const int nitem = last ? item + K : item, np = last ? 0 : pass + 1;
-    const bool more = nitem < nitems;
+    const int nitem = last ? item + 1 : item, np = last ? 0 : pass + 1;
+    const bool more = nitem < end;
     // the three youngest waves derive their queries in float + five ds_bpermute and are the last to have their loads out:
     // they go ahead of the other waves' flush (312.8 -> 308.6 us, A/B on one box)
     if (!l0) __builtin_amdgcn_s_setprio(2);
     if (more) {
       const int b2 = to_sgpr((int)(((float)nitem + 0.5f) * __builtin_amdgcn_rcpf((float)ntiles)));
       const int64_t pair_img2 = (int64_t)b2 * d.Lq * M + m;
-      const int tile2 = nitem - b2 * ntiles;
-      const int ty2 = to_sgpr((int)(((float)tile2 + 0.5f) * __builtin_amdgcn_rcpf((float)TX)));
-      const int tx2 = tile2 - ty2 * TX;
+      const int tile2 = nitem - b2 * ntiles;                  // tile column by tile column, down the column
+      const int tx2 = to_sgpr((int)(((float)tile2 + 0.5f) * __builtin_amdgcn_rcpf((float)TY)));
+      const int ty2 = tile2 - tx2 * TY;
         // ---- this quad's query --------------------------------------------------------------------------------------
         uint32_t qidx;
         if (l0) {
@@ -677,24 +755,15 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
     if (body && last) {
       // #4: every wave's atomics are in.  The next item's queries and loads above do not depend on it: the waves of levels 1..3,
       // which finish the pass first, derive theirs while the level-0 waves are still in the pass instead of behind the barrier.
+      // The accumulators stay where they are: the next step's transition moves or flushes them behind its window DMA.
       lds_barrier();
       BW_STAMP(12);
-      // ---- flush: every touched accumulator pixel inside the image leaves as one full-line float atomic (32 lanes x 4 B) ----
-      {
-        const int ch = tid & 31;
-  #pragma unroll 3
-        for (int p = tid >> 5; p < kSlots; p += kT / 32) {
-          // read and clear in one LDS operation: the next item finds the windows zeroed
-          const int raw = __hip_atomic_exchange(reinterpret_cast<lds_int_ptr>((uintptr_t)(smem_base + kAccOff + p * 128 + ch * 4)), 0,
-                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          const uint32_t off = mt.off_tab[p];
-          if (off != 0xffffffffu && raw != 0)
-            atomic_add(reinterpret_cast<float*>(gv_head + (size_t)off) + ch, (float)raw * inv_scale);
-        }
-      }
       BW_STAMP(13);
     }
-    if (!more) break;
+    if (!more) {
+      if (tail || !body) break;
+      tail = true;                                           // one more step: the transition alone, everything leaves
+    }
     item = nitem; pass = np; body = true;
   }
 }

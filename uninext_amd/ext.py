@@ -449,6 +449,64 @@ def aligned_bilinear_forward(x, factor):
     return out
 
 
+def dynmask_backward(mask_feats, inst_xy, params, num_insts, stride, rel_coord, grad_logits, need_xy=True):
+    """Backward of dynmask_forward (include/dynmask_hip.h: dynmask_hip_backward_f32): grad_logits [n_inst, H, W] ->
+    (grad_mask_feats [N, 8, H, W], grad_params [n_inst, P], grad_inst_xy [n_inst, 2] or None).  Deterministic (no float
+    atomics); the activations are recomputed, the workspace (partial sums of the pixel slices) comes from PyTorch's
+    caching allocator for the duration of the call."""
+    lib = _lib.load()
+    dev = mask_feats.device
+    for name, t in (("mask_feats", mask_feats), ("inst_xy", inst_xy), ("params", params), ("grad_logits", grad_logits)):
+        _check(name, t, dev)
+        if t.dtype != torch.float32:
+            raise RuntimeError("%s must be float32" % name)
+    N, C, H, W = mask_feats.shape
+    counts = [int(n) for n in num_insts]
+    n_all = sum(counts)
+    want = (C + 2 if rel_coord else C) * 8 + 8 * 8 + 8 + 8 + 8 + 1
+    if len(counts) != N or inst_xy.shape != (n_all, 2) or params.shape != (n_all, want) or grad_logits.shape != (n_all, H, W):
+        raise RuntimeError("dynmask_backward: inconsistent shapes")
+    if N > _lib.DYNMASK_BWD_MAX_BATCH:
+        raise RuntimeError("dynmask_backward: at most %d images per call" % _lib.DYNMASK_BWD_MAX_BATCH)
+    g_feats = torch.empty_like(mask_feats)
+    g_params = torch.empty_like(params)
+    g_xy = torch.empty_like(inst_xy) if need_xy else None
+    ws_bytes = int(lib.dynmask_hip_backward_workspace_bytes(n_all, H, W))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+    arr = (ctypes.c_int * max(N, 1))(*counts)
+    with torch.cuda.device(dev):
+        rc = lib.dynmask_hip_backward_f32(mask_feats.data_ptr(), inst_xy.data_ptr(), params.data_ptr(), arr, N, C, H, W, int(stride),
+                                          int(bool(rel_coord)), grad_logits.data_ptr(), g_feats.data_ptr(), g_params.data_ptr(),
+                                          g_xy.data_ptr() if g_xy is not None else None, ws.data_ptr(), ws_bytes,
+                                          ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc != 0:
+        _raise(rc)
+    return g_feats, g_params, g_xy
+
+
+def aligned_bilinear_backward(grad_out, factor):
+    """Backward of aligned_bilinear_forward: grad_out [n, 1, f h, f w] or [n, f h, f w] -> the input's gradient."""
+    lib = _lib.load()
+    _check("grad_out", grad_out, grad_out.device)
+    if grad_out.dtype != torch.float32:
+        raise RuntimeError("grad_out must be float32")
+    squeeze = grad_out.dim() == 4
+    if squeeze and grad_out.shape[1] != 1:
+        raise RuntimeError("aligned_bilinear_backward: expected [n, 1, H, W]")
+    f = int(factor)
+    n, oh, ow = grad_out.shape[0], grad_out.shape[-2], grad_out.shape[-1]
+    if f < 1 or oh % f or ow % f:
+        raise RuntimeError("aligned_bilinear_backward: the gradient's size is not a multiple of the factor")
+    h, w = oh // f, ow // f
+    out = torch.empty((n, 1, h, w) if squeeze else (n, h, w), dtype=torch.float32, device=grad_out.device)
+    with torch.cuda.device(grad_out.device):
+        rc = lib.aligned_bilinear_hip_backward_f32(grad_out.data_ptr(), n, h, w, f, out.data_ptr(),
+                                                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc != 0:
+        _raise(rc)
+    return out
+
+
 def patch_embed_supported(x, weight, stride, padding):
     """True when include/patch_embed_hip.h has a kernel for this convolution (fp32, GPU, kernel == stride, no pad)."""
     if not (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4 and weight.dim() == 4):

@@ -4,12 +4,13 @@ Host-side mirror of `DDETRSegmUniDN.dynamic_mask_with_coords` (projects/UNINEXT/
 and of the helpers it uses (`mask_heads_forward` :734-752, `parse_dynamic_params` :1148-1171, `aligned_bilinear`
 :1174-1196, `compute_locations` :1199-1212): same arguments, same output `[1, n_inst_all, H*f, W*f]`.
 
-Inference on the GPU (fp32, 8 mask-feature channels, no gradients needed) runs two HIP kernels
-(include/dynmask_hip.h): the three per-instance 1x1 convolutions with the relative-coordinate channels generated on
-the fly -- the reference's `[1, n_inst*(C+2), H, W]` repeat/cat input (1.2 GB at 1800 instances) is never built --
-and `aligned_bilinear`.  When gradients are required (training) or the geometry is unsupported, a PyTorch
-composition is used that is algebraically the same but also non-materialising: the feature part of the first layer
-is one batched matmul against the shared feature map.  `use_raft` up-sampling is not covered (USE_RAFT is False in
+On the GPU (fp32, 8 mask-feature channels) it runs HIP kernels (include/dynmask_hip.h): the three per-instance 1x1
+convolutions with the relative-coordinate channels generated on the fly -- the reference's `[1, n_inst*(C+2), H, W]`
+repeat/cat input (1.2 GB at 1800 instances) is never built -- and `aligned_bilinear`; UNDER AUTOGRAD TOO (round 5:
+`DynMaskFunction`, `AlignedBilinearFunction` -- BASELINE configs[4] trains this head): the backward kernels recompute
+the activations per (instance, pixel), so nothing of size n_inst x 8 x H x W is kept for backward either, and they are
+deterministic.  For other geometry / dtypes / CPU tensors a PyTorch composition is used that is algebraically the same
+and also non-materialising: the feature part of the first layer is one batched matmul against the shared feature map.  `use_raft` up-sampling is not covered (USE_RAFT is False in
 every shipped config, uninext/config.py:178).
 """
 import os
@@ -51,13 +52,29 @@ def _aligned_bilinear_torch(tensor, factor):
     return t[:, :, :factor * h, :factor * w]
 
 
+class AlignedBilinearFunction(torch.autograd.Function):
+    """aligned_bilinear (ddetrs_dn.py:1174-1196) of a [n, 1, h, w] fp32 GPU tensor with its gradient: both are one HIP kernel
+    (include/dynmask_hip.h); the backward is a fixed-order gather, bitwise repeatable."""
+
+    @staticmethod
+    def forward(ctx, tensor, factor):
+        ctx.factor = int(factor)
+        return _ext.aligned_bilinear_forward(tensor.contiguous(), ctx.factor)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out):
+        return _ext.aligned_bilinear_backward(grad_out.contiguous(), ctx.factor), None
+
+
 def aligned_bilinear(tensor, factor):
     assert tensor.dim() == 4 and factor >= 1 and int(factor) == factor
     factor = int(factor)
     if factor == 1:
         return tensor
-    needs_grad = torch.is_grad_enabled() and tensor.requires_grad
-    if tensor.is_cuda and tensor.dtype == torch.float32 and tensor.shape[1] == 1 and not needs_grad:
+    if tensor.is_cuda and tensor.dtype == torch.float32 and tensor.shape[1] == 1:
+        if torch.is_grad_enabled() and tensor.requires_grad:
+            return AlignedBilinearFunction.apply(tensor, factor)
         return _ext.aligned_bilinear_forward(tensor.contiguous(), factor)
     return _aligned_bilinear_torch(tensor, factor)
 
@@ -73,24 +90,54 @@ def _dynamic_convs_torch(mask_feats, inst_xy, params, num_insts, stride, rel_coo
         feat = mask_feats[b].reshape(c, h * w)                           # shared by the image's instances
         h0 = torch.matmul(w0[sl, :, (2 if rel_coord else 0):], feat) + b0[sl, :, None]
         if rel_coord:
-            rel = inst_xy[sl, None, :] - loc[None, :, :]                 # [cnt, HW, 2]
-            h0 = h0 + torch.matmul(w0[sl, :, :2], rel.transpose(1, 2))
+            rel = (inst_xy[sl, None, :] - loc[None, :, :]).float()        # [cnt, HW, 2]; `.float()` as ddetrs_dn.py:783
+            h0 = h0 + torch.matmul(w0[sl, :, :2], rel.transpose(1, 2).to(w0.dtype))
         h1 = torch.relu(torch.bmm(w1[sl], torch.relu(h0)) + b1[sl, :, None])
         outs.append((torch.bmm(w2[sl], h1) + b2[sl, :, None]).reshape(cnt, h, w))
         first += cnt
     return torch.cat(outs, 0) if outs else mask_feats.new_zeros((0, h, w))
 
 
+class DynMaskFunction(torch.autograd.Function):
+    """`apply(mask_feats [N, 8, H, W], inst_xy [n, 2], params [n, P], counts (tuple of ints), stride, rel_coord)` -> mask logits
+    [n, H, W]: the three per-instance 1x1 convolutions of mask_heads_forward (ddetrs_dn.py:734-752) on the inputs of :765-808, and
+    their gradients with respect to the mask features, the instance parameters and the instance reference points
+    (include/dynmask_hip.h: dynmask_hip_backward_f32).  Saved for backward: the three inputs only."""
+
+    @staticmethod
+    def forward(ctx, mask_feats, inst_xy, params, counts, stride, rel_coord):
+        mask_feats, inst_xy, params = mask_feats.contiguous(), inst_xy.contiguous(), params.contiguous()
+        ctx.counts, ctx.stride, ctx.rel_coord = tuple(int(c) for c in counts), int(stride), bool(rel_coord)
+        ctx.save_for_backward(mask_feats, inst_xy, params)
+        return _ext.dynmask_forward(mask_feats, inst_xy, params, ctx.counts, ctx.stride, ctx.rel_coord)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_logits):
+        mask_feats, inst_xy, params = ctx.saved_tensors
+        g_feats, g_params, g_xy = _ext.dynmask_backward(mask_feats, inst_xy, params, ctx.counts, ctx.stride, ctx.rel_coord,
+                                                        grad_logits.contiguous(), need_xy=ctx.needs_input_grad[1])
+        return (g_feats if ctx.needs_input_grad[0] else None, g_xy if ctx.needs_input_grad[1] else None,
+                g_params if ctx.needs_input_grad[2] else None, None, None, None)
+
+
 def dynamic_mask_logits(mask_feats, reference_points, mask_head_params, num_insts, mask_feat_stride, rel_coord=True):
     """Mask logits at the feature stride, [n_inst_all, 1, H, W] (ddetrs_dn.py:765-822)."""
     n_img, c, h, w = mask_feats.shape
-    inst_xy = reference_points.reshape(-1, 2).float()
+    inst_xy = reference_points.reshape(-1, 2)
+    if inst_xy.dtype not in (torch.float32, torch.float64):
+        inst_xy = inst_xy.float()
     params = torch.flatten(mask_head_params, 0, 1)
     counts = [int(n) for n in num_insts]
     needs_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (mask_feats, reference_points, mask_head_params))
-    if _ext.dynmask_supported(mask_feats) and not needs_grad and params.dtype == torch.float32:
-        logits = _ext.dynmask_forward(mask_feats.contiguous(), inst_xy.contiguous(), params.contiguous(), counts,
-                                      mask_feat_stride, rel_coord)
+    if _ext.dynmask_supported(mask_feats) and params.dtype == torch.float32 and inst_xy.dtype == torch.float32 \
+            and inst_xy.is_cuda and params.is_cuda \
+            and not (needs_grad and (len(counts) > _ext._lib.DYNMASK_BWD_MAX_BATCH or torch.is_autocast_enabled())):
+        if needs_grad:
+            logits = DynMaskFunction.apply(mask_feats, inst_xy, params, tuple(counts), mask_feat_stride, rel_coord)
+        else:
+            logits = _ext.dynmask_forward(mask_feats.contiguous(), inst_xy.contiguous(), params.contiguous(), counts,
+                                          mask_feat_stride, rel_coord)
     else:
         logits = _dynamic_convs_torch(mask_feats, inst_xy, params, counts, mask_feat_stride, rel_coord)
     return logits.reshape(-1, 1, h, w)
