@@ -80,10 +80,10 @@ def test_full_size_r50_head(dev):
             torch.nn.init.uniform_(m.bias, -0.1, 0.1)
     x = [torch.randn(2, 256, h, w, device=dev) for h, w in ((100, 167), (50, 84), (25, 42))]
     with torch.no_grad():
+        head.exact_fp32 = False
         out = head(x, None)                                          # HIP route: split-bf16 from packed weights
-        head.exact_fp32, head.exact_impl = True, "mfma"
-        out_exact = head(x, None)                                    # HIP route: exact-fp32 MFMA
-        head.exact_fp32, head.exact_impl = False, None
+        head.exact_fp32 = True
+        out_exact = head(x, None)                                    # the default: fp32 through MIOpen
         F = torch.nn.functional
         f = F.relu(head.lay3(x[-1]))
         f = F.relu(head.lay4(x[-2] + F.interpolate(f, size=x[-2].shape[-2:], mode="nearest")))

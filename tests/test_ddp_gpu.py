@@ -116,10 +116,14 @@ def _bench_ddp_worker(rank, world, port, q):
     torch.cuda.set_device(0)
     import bench
     bench.DDP_GRAD_BYTES = 2 * bench.DDP_BUCKET_BYTES + 1          # three buckets: keep the gloo round trips short
-    enc, dec = bench.build_inputs("model", rank)
-    res = bench.measure_ddp(enc[:1], dec[:1], world, reps=1)
-    st = bench.measure_train_step(enc[:1], dec[:1], world, reps=1)
-    q.put((rank, res, st))
+    try:
+        enc, dec = bench.build_inputs("model", rank)
+        sync = bench.RankSync(world)                                # the legs are generators: run_leg meets the other rank at their yields
+        res = bench.run_leg(sync, lambda: bench.measure_ddp(enc[:1], dec[:1], world, reps=1))
+        st = bench.run_leg(sync, lambda: bench.measure_train_step(enc[:1], dec[:1], world, reps=1))
+        q.put((rank, res, st))
+    except Exception as e:  # noqa: BLE001  (a worker that dies silently costs the parent its whole queue timeout)
+        q.put((rank, {"error": repr(e)}, {"error": repr(e)}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -133,11 +137,12 @@ def test_bench_ddp_leg_runs_on_two_ranks():
     procs = [ctx.Process(target=_bench_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=900) for _ in procs), key=lambda r: r[0])
+    res = sorted((q.get(timeout=300) for _ in procs), key=lambda r: r[0])
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
     for rank, ddp, st in res:
+        assert "error" not in ddp and "error" not in st, (rank, ddp, st)
         assert ddp["buckets"] == 3 and ddp["allreduce_ms"] > 0 and ddp["overlapped_ms"] > 0 and ddp["op_fwd_bwd_ms"] > 0
         assert st["ms_per_step"] > 0
     assert res[0][1]["allreduce_ms"] == res[1][1]["allreduce_ms"]          # MAX over ranks on every rank

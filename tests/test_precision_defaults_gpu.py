@@ -70,7 +70,7 @@ def test_msdeformattn_layer_at_trained_scales(fast, dev):
     assert err < (1e-4 if fast else 2e-5) * scale, (err, scale)
 
 
-@pytest.mark.parametrize("exact", [True, "mfma", False])
+@pytest.mark.parametrize("exact", [True, False])
 def test_mask_head_at_trained_scales(exact, dev):
     from uninext_amd.mask_head import MaskHeadSmallConv
     gen = torch.Generator().manual_seed(6)
@@ -85,18 +85,18 @@ def test_mask_head_at_trained_scales(exact, dev):
     with torch.no_grad():
         want = head.double()([t.double() for t in x], None)
     head = head.float().to(dev)
-    old = (MaskHeadSmallConv.exact_fp32, MaskHeadSmallConv.exact_impl)
-    # True: the default -- fp32 through the MIOpen convolutions; "mfma": this library's exact-fp32 MFMA kernel; False: split-bf16
-    MaskHeadSmallConv.exact_fp32, MaskHeadSmallConv.exact_impl = bool(exact), ("mfma" if exact == "mfma" else None)
+    old = MaskHeadSmallConv.exact_fp32
+    # True: the default -- fp32 through the MIOpen convolutions; False: split-bf16 (this library's MFMA kernels)
+    MaskHeadSmallConv.exact_fp32 = bool(exact)
     try:
         with torch.no_grad():
             got = head([t.to(dev) for t in x], None)
     finally:
-        MaskHeadSmallConv.exact_fp32, MaskHeadSmallConv.exact_impl = old
+        MaskHeadSmallConv.exact_fp32 = old
     scale = float(want.abs().max())
     err = float((got.double().cpu() - want).abs().max())
     print("MaskHeadSmallConv %s: max |err| %.3e = %.2e of the output scale %.1f" % (
-        {True: "fp32 (default, MIOpen)", "mfma": "fp32 (exact MFMA kernel)", False: "split-bf16"}[exact], err, err / scale, scale))
+        {True: "fp32 (default, MIOpen)", False: "split-bf16"}[exact], err, err / scale, scale))
     assert err < (1e-5 if exact else 1e-4) * scale, (err, scale)
 
 

@@ -476,9 +476,7 @@ conv3x3_exact(const float* __restrict__ in, const float* __restrict__ packed, co
   constexpr int kHalo = (TH + 2) * kHaloW;                                   // halo pixels of the tile
   // pixel pitch 80 bytes, not 64: a ds_read_b128 is served 16 lanes at a time = 16 consecutive halo pixels, and 16 x 64 B covers
   // only a quarter of the banks (4-way conflicts: 74 % of the LDS-active cycles, profiles/r04_conv3x3_exact.txt); 5 x 16 B is odd
-#ifndef CONV3X3_EXACT_PITCH
-#define CONV3X3_EXACT_PITCH 20
-#endif
+constexpr int CONV3X3_EXACT_PITCH = 20;
   constexpr int kPitch = CONV3X3_EXACT_PITCH;                               // floats per halo pixel in the LDS
   __shared__ __attribute__((aligned(16))) float As[2][kHalo][kPitch];       // [buffer][halo pixel][(h, s)]
 
@@ -554,9 +552,6 @@ conv3x3_exact(const float* __restrict__ in, const float* __restrict__ packed, co
   // Everything an MFMA waits for is requested a long way ahead: the NINE taps' weights of chunk c + 1 while chunk c is multiplied
   // (72 registers; two taps ahead -- ~2000 clocks -- was inside the L2's latency under load), the halo of chunk c + 1 likewise, and
   // the pixel fragments of tap t + 1 before the MFMAs of tap t (CONV3X3_EXACT_AHEAD=0: the round-4 first version, for A/B).
-#ifndef CONV3X3_EXACT_AHEAD
-#define CONV3X3_EXACT_AHEAD 1
-#endif
   struct XFrag { f32x4 a[TI], b[TI]; };
   auto load_x = [&](int buf, int tap, XFrag& x) {        // tap compile-time after unrolling
     const int toff = ((tap / 3) * kHaloW + (tap % 3)) * kPitch;
@@ -578,7 +573,6 @@ conv3x3_exact(const float* __restrict__ in, const float* __restrict__ packed, co
           acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(s < 4 ? wf.a[jn][s & 3] : wf.b[jn][s & 3],
                                                             s < 4 ? x.a[i][s & 3] : x.b[i][s & 3], acc[i][jn], 0, 0, 0);
   };
-#if CONV3X3_EXACT_AHEAD
   WFrag wc[9], wnx[9];
   load_halo(0);
 #pragma unroll
@@ -607,30 +601,6 @@ conv3x3_exact(const float* __restrict__ in, const float* __restrict__ packed, co
 #pragma unroll
     for (int t = 0; t < 9; ++t) wc[t] = wnx[t];
   }
-#else
-  WFrag w0, w1, w2;
-  load_halo(0);
-  load_w(0, w0);
-  load_w(1, w1);
-  store_halo(0);
-  __syncthreads();
-  XFrag xs;
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
-    const int buf = chunk & 1, ft = chunk * 9;
-    if (chunk + 1 < nchunks) load_halo(chunk + 1);
-#pragma unroll
-    for (int t3 = 0; t3 < 3; ++t3) {                   // ring of three weight register sets, loads two taps ahead
-      load_w(ft + 3 * t3 + 2, w2);
-      load_x(buf, 3 * t3, xs); tap_mfma(xs, w0);
-      load_w(ft + 3 * t3 + 3, w0);
-      load_x(buf, 3 * t3 + 1, xs); tap_mfma(xs, w1);
-      load_w(ft + 3 * t3 + 4, w1);
-      load_x(buf, 3 * t3 + 2, xs); tap_mfma(xs, w2);
-    }
-    if (chunk + 1 < nchunks) store_halo(buf ^ 1);
-    __syncthreads();
-  }
-#endif
 
   // ---- epilogue: accumulator register v of lane l is (channel row 8 (v / 4) + 4 (l / 32) + v % 4, pixel l % 32) ------
 #pragma unroll
@@ -741,7 +711,7 @@ int conv3x3_hip_f32(const float* in, const float* weight, const float* bias, int
     return rc == 0 ? 0 : dynmask_set_error(rc, hipGetErrorString((hipError_t)rc));
   }
   // 128 x 128 tiles unless they would leave CUs without a workgroup or most of a 128-channel tile empty
-  static const int forced = std::getenv("CONV3X3_TILE") ? std::atoi(std::getenv("CONV3X3_TILE")) : 0;
+  static const int forced = msda::ab_env_int("CONV3X3_TILE", 0);
   const long long tiles128 = ((M + 127) / 128) * ((cout + 127) / 128);
   bool big = cout > 64 && tiles128 >= 256;
   if (forced == 1) big = true;
@@ -787,7 +757,7 @@ int conv3x3_hip_packed_f32(const float* in, const void* packed, const float* bia
   const uint32_t* pk = static_cast<const uint32_t*>(packed);
   hipStream_t st = (hipStream_t)stream;
   // 128 output channels per workgroup unless that leaves CUs idle (small feature maps): then 64
-  static const int forced_tj = std::getenv("CONV3X3_TJ") ? std::atoi(std::getenv("CONV3X3_TJ")) : 0;
+  static const int forced_tj = msda::ab_env_int("CONV3X3_TJ", 0);
   bool wide = cout > 64 && tiles * ((cout + 127) / 128) >= 512;
   if (forced_tj == 1) wide = false;
   if (forced_tj == 2) wide = cout > 64;
@@ -842,7 +812,7 @@ int conv3x3_hip_packed_exact_f32(const float* in, const void* packed, const floa
   // Work units: the kernel runs at the matrix pipe's rate, so what decides the time is how evenly (tile, channel group) units
   // spread over the SIMDs.  Largest unit (8 x 16 pixels x 128 channels: best weight-fragment reuse) when there are >= 4 per
   // workgroup slot of the chip, then 8 x 16 x 64, else 4 x 16 x 64 -- CONV3X3_EXACT_UNIT=1|2|3 pins one (A/B).
-  static const int forced = std::getenv("CONV3X3_EXACT_UNIT") ? std::atoi(std::getenv("CONV3X3_EXACT_UNIT")) : 0;
+  static const int forced = msda::ab_env_int("CONV3X3_EXACT_UNIT", 0);
   int unit = 3;
   if (cout > 64 && tiles * ((cout + 127) / 128) >= 2048) unit = 1;
   else if (tiles * ((cout + 63) / 64) >= 2048) unit = 2;

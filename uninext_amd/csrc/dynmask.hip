@@ -388,8 +388,7 @@ std::atomic<const char*> g_last_kernel{""};
 int current_variant() {
   int v = g_variant.load(std::memory_order_relaxed);
   if (v < 0) {
-    const char* e = std::getenv("DYNMASK_HIP_VARIANT");
-    v = e ? std::atoi(e) : 0;
+    v = msda::ab_env_int("DYNMASK_HIP_VARIANT", 0);
     if (v < 0 || v >= kNumVariants) v = 0;
     g_variant.store(v, std::memory_order_relaxed);
   }

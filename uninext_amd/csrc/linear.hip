@@ -618,7 +618,7 @@ static int linear_impl(const float* x, const float* x2, const void* packed, cons
   const int n_pad = linear::n_padded(out_features);
   const uint32_t* pk = static_cast<const uint32_t*>(packed);
   hipStream_t st = (hipStream_t)stream;
-  static const int forced_tj = std::getenv("LINEAR_TJ") ? std::atoi(std::getenv("LINEAR_TJ")) : 0;   // A/B hook: 1, 2, 4
+  static const int forced_tj = msda::ab_env_int("LINEAR_TJ", 0);   // A/B hook: 1, 2, 4
   // (the packed weights are padded to 128 columns only: a 256-column workgroup needs out_features % 256 == 0)
   const bool wide_ok = out_features % 256 == 0 && mt * (out_features / 256) >= 512 && split_col % 256 == 0;
   if (wide_ok && (forced_tj == 4 || (forced_tj == 0 && out_features == 256))) {
@@ -709,7 +709,7 @@ int linear_hip_packed_ffn_f32(const float* x, const void* packed1, const float* 
   const uint32_t* p1 = static_cast<const uint32_t*>(packed1);
   const uint32_t* p2 = static_cast<const uint32_t*>(packed2);
   const int f_pad = linear::n_padded(d_ffn);
-  static const int forced_nw = std::getenv("LINEAR_FFN_WAVES") ? std::atoi(std::getenv("LINEAR_FFN_WAVES")) : 0;   // A/B hook
+  static const int forced_nw = msda::ab_env_int("LINEAR_FFN_WAVES", 0);   // A/B hook
   const bool eight = d_ffn % 256 == 0 && forced_nw != 4;
   static std::atomic<uint64_t> opted_in[4];
   auto launch = [&](auto kernel, int nw, std::atomic<uint64_t>& done) -> int {

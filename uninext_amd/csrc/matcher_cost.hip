@@ -84,17 +84,3 @@ extern "C" int matcher_cost_hip_f32(const float* logits, const float* boxes, con
   return e == hipSuccess ? 0 : dynmask_set_error((int)e, hipGetErrorString(e));
 }
 
-#ifdef MATCHER_COST_DEBUG
-// debug builds only (tools/matcher_cost_dbg.py): the elementary functions, to hold against those of PyTorch
-__global__ void matcher_cost_unary(const float* x, int n, int op, float* y) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float v = x[i];
-  y[i] = op == 0 ? expf(-v) : op == 1 ? logf(v) : op == 2 ? 1.0f / (1.0f + expf(-v)) : op == 3 ? __expf(-v) : op == 4 ? __logf(v)
-       : op == 5 ? 1.0f / (1.0f + __expf(-v)) : __frcp_rn(1.0f + expf(-v));
-}
-extern "C" int matcher_cost_debug_unary_f32(const float* x, int n, int op, float* y, void* stream) {
-  hipLaunchKernelGGL(matcher_cost_unary, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), x, n, op, y);
-  return (int)hipGetLastError();
-}
-#endif

@@ -19,13 +19,9 @@
 namespace msda {
 namespace {
 
-#ifndef MSDA_BWD_DEC_THREADS
-#define MSDA_BWD_DEC_THREADS 1024
-#endif
+constexpr int MSDA_BWD_DEC_THREADS = 1024;
 constexpr int kDT = MSDA_BWD_DEC_THREADS;                                  // threads per workgroup = 32 half-waves = 32 pairs in flight
-#ifndef MSDA_BWD_DEC_SLOTS
-#define MSDA_BWD_DEC_SLOTS 1200
-#endif
+constexpr int MSDA_BWD_DEC_SLOTS = 1200;
 constexpr int kAccSlots = MSDA_BWD_DEC_SLOTS;              // accumulator slots (pixels) of 32 int32: 150 KB
 struct DMeta { unsigned gmax_bits, amax_bits; };
 constexpr int kDecLds = kAccSlots * 128 + 16;
@@ -214,7 +210,7 @@ msda_bwd_dec(const float* __restrict__ grad_out, const float* __restrict__ value
 // MSDA_BWD_DEC_SLICES=n: A/B switch for the first rule.
 constexpr int kDecSliceQueries = 256, kDecMaxSlices = 64;
 static int dec_slices(const Dims& d) {
-  static const int env = std::getenv("MSDA_BWD_DEC_SLICES") ? std::atoi(std::getenv("MSDA_BWD_DEC_SLICES")) : 0;
+  static const int env = ab_env_int("MSDA_BWD_DEC_SLICES", 0);
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   const int64_t heads = std::max<int64_t>(1, (int64_t)d.M * d.N);

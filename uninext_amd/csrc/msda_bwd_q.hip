@@ -18,9 +18,7 @@
 namespace msda {
 namespace {
 
-#ifndef MSDA_BWD_Q_THREADS
-#define MSDA_BWD_Q_THREADS 768
-#endif
+constexpr int MSDA_BWD_Q_THREADS = 768;
 constexpr int kQT = MSDA_BWD_Q_THREADS, kQG = 8, kQPairs = kQT / kQG;
 constexpr int kQSlots = 280;                                     // resident pixels of the last level (35 KB) + one all-zero slot
 constexpr int kQRecPair = 8 * 32 + 16;                           // eight 32-byte sample records per pair (+ 16: bank skew)

@@ -221,9 +221,7 @@ msda_bwd_regions_scan(const int64_t* __restrict__ shapes, Dims d, uint32_t* __re
 // = channel: the 32 lanes add 256 contiguous bytes, every LDS bank once), kAddUnroll records of a half wave in flight -- the
 // records are read in order but their grad_output rows are a gather, and one row at a time per half wave is what a first
 // version spent 1.6 of its 2.0 ms on.
-#ifndef MSDA_REGIONS_UNROLL
-#define MSDA_REGIONS_UNROLL 4
-#endif
+constexpr int MSDA_REGIONS_UNROLL = 4;
 constexpr int kAddT = 1024, kAddHalfWaves = kAddT / 32, kAddUnroll = MSDA_REGIONS_UNROLL;
 __global__ void __launch_bounds__(kAddT)
 msda_bwd_regions_add(const float* __restrict__ grad_out, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
@@ -344,11 +342,7 @@ int launch_backward_regions(const float* grad_out, const float* value, const int
     return launch_backward_tiled(grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, stream);
   };
   if (kernel_name) *kernel_name = "msda_bwd_regions";
-  static const int hist_cap = [] {   // tests of the path without the LDS table
-    const char* e = std::getenv("MSDA_BWD_REGIONS_HIST");
-    const int v = e ? std::atoi(e) : kHistCap;
-    return std::max(0, std::min(v, kHistCap));
-  }();
+  static const int hist_cap = std::max(0, std::min(ab_env_int("MSDA_BWD_REGIONS_HIST", kHistCap), kHistCap));   // (the path without the LDS table)
   int dev = 0;
   if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return (int)e;
   if (dev < 0 || dev >= kMaxDevices) return (int)hipErrorInvalidDevice;
@@ -411,7 +405,7 @@ int launch_backward_regions(const float* grad_out, const float* value, const int
   if (hipError_t e = hipMemsetAsync(counts, 0, b_counts, stream); e != hipSuccess) return (int)e;
 
   // the query side: msda_bwd_q (round 4; MSDA_BWD_REGIONS_Q=0: msda_bwd_tiled with its grad_value half compiled out, A/B)
-  static const bool q_pass = !(std::getenv("MSDA_BWD_REGIONS_Q") && std::getenv("MSDA_BWD_REGIONS_Q")[0] == '0');
+  static const bool q_pass = ab_env_int("MSDA_BWD_REGIONS_Q", 1) != 0;
   if (q_pass && q_backward_ok(d)) {
     if (int rc = launch_backward_q(grad_out, value, shapes, lsi, loc, attn, d, grad_loc, grad_attn, stream)) return rc;
   } else if (int rc = launch_backward_tiled_nogv(grad_out, value, shapes, lsi, loc, attn, d, grad_loc, grad_attn, stream)) {

@@ -83,10 +83,6 @@ __device__ __forceinline__ float group8_sum(float v) {  // over the 8 lanes of a
 
 typedef int __attribute__((address_space(3)))* lds_int_ptr;
 __device__ __forceinline__ void lds_add(uint32_t lds_byte_addr, int v) {   // ds_add_u32, no return value
-#ifdef MSDA_BWD_NOADD   // timing experiment only (wrong results): the value-gradient accumulation is dropped
-  asm volatile("" :: "v"(lds_byte_addr), "v"(v));
-  return;
-#endif
   __hip_atomic_fetch_add(reinterpret_cast<lds_int_ptr>((uintptr_t)lds_byte_addr), v, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -434,20 +430,11 @@ __device__ __forceinline__ void bwd_tiled_body(const float* __restrict__ grad_ou
             const float pa = fmaf(lh, ab_, hh * at_), pwx = a * fmaf(lh, db_, hh * dt_), phy = a * (ab_ - at_);
             // near samples: accumulate into the LDS window; dead corners and far samples go to the pair's sink slot
             const v2f wh = v2f{hh, lh} * hw, wl = v2f{hh, lh} * lw;      // (w1, w3), (w2, w4)
-#ifdef MSDA_BWD_NOCONF   // timing experiment only (wrong results): every ds_add conflict-free by construction
-            const uint32_t a1 = smem_base + (uint32_t)lane * 4u, a2 = a1 + 1024u, a3 = a1 + 2048u, a4 = a1 + 3072u;
-            asm volatile("" :: "v"(cur.ak[0]), "v"(cur.ak[1]), "v"(cur.ak[2]), "v"(cur.ak[3]));
-#else
             const uint32_t a1 = cur.ak[0] + lane_off, a2 = cur.ak[1] + lane_off, a3 = cur.ak[2] + lane_off, a4 = cur.ak[3] + lane_off;
-#endif
 #pragma unroll
             for (int cp = 0; GV && cp < 2; ++cp) {
               const v2f g1 = tgs[cp] * wh.x, g2 = tgs[cp] * wl.x, g3 = tgs[cp] * wh.y, g4 = tgs[cp] * wl.y;
-#ifdef MSDA_BWD_NOCONF
-              constexpr uint32_t kC0 = 256u, kC1 = 512u;
-#else
               constexpr uint32_t kC0 = 8u, kC1 = 4u;
-#endif
               lds_add(a1 + kC0 * cp, cvt_rn_i32(g1.x)); lds_add(a1 + kC0 * cp + kC1, cvt_rn_i32(g1.y));
               lds_add(a2 + kC0 * cp, cvt_rn_i32(g2.x)); lds_add(a2 + kC0 * cp + kC1, cvt_rn_i32(g2.y));
               lds_add(a3 + kC0 * cp, cvt_rn_i32(g3.x)); lds_add(a3 + kC0 * cp + kC1, cvt_rn_i32(g3.y));
@@ -469,9 +456,6 @@ __device__ __forceinline__ void bwd_tiled_body(const float* __restrict__ grad_ou
           // -- far samples of this pass: the value gradient w_k * a * g_c does not depend on the sampled values,
           //    so a half-wave (32 lanes = 32 channels) redoes it from the record and the upstream gradient and
           //    issues ONE full-line atomic per live corner.
-#ifdef MSDA_BWD_NOFAR   // timing experiment only (wrong results): far samples are dropped
-          far_any = 0;
-#endif
           if (far_any) {
             const int hl = lane & 31;
 #pragma unroll 1

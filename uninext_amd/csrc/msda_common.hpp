@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <cstdlib>
 
 namespace msda {
 
@@ -96,6 +97,19 @@ inline int ensure_dynamic_lds(const void* kernel, int bytes, std::atomic<uint64_
   done.fetch_or(bit, std::memory_order_release);
   return 0;
 }
+
+// A/B hooks of the kernels (tile shapes, grid forms, alternative passes): the PRODUCT library reads no such environment
+// variable -- ab_env_int folds to its default at compile time; `make experiments` (-DMSDA_EXPERIMENTS) builds the library that
+// honours them, to repeat the measurements recorded under profiles/.  The supported switches are the ones listed in
+// INTEGRATION.md ("Environment").
+#ifdef MSDA_EXPERIMENTS
+inline int ab_env_int(const char* name, int dflt) {
+  const char* e = std::getenv(name);
+  return e ? std::atoi(e) : dflt;
+}
+#else
+constexpr int ab_env_int(const char*, int dflt) { return dflt; }
+#endif
 
 // Variant numbering shared with include/msda_hip.h.
 enum Variant { kAuto = 0, kGeneric = 1, kLaneGroup = 2, kTiled = 3, kTiledL0 = 4, kTiledL0Big = 5, kLaneGroupCL = 6,

@@ -313,7 +313,7 @@ bool fused_forward_hm_ok(const Dims& d, int ref_dim) { return fused_forward_ok(d
 int launch_forward_fused(int variant, const float* value, int head_major, const int64_t* shapes, const int64_t* lsi,
                          const float* ref_points, int ref_dim, const float* offsets, const float* logits, const Dims& d,
                          float* out, hipStream_t stream, const char** kernel_name) {
-  static const bool use_lg3 = !(std::getenv("MSDA_HIP_FUSED_LG3") && std::getenv("MSDA_HIP_FUSED_LG3")[0] == '0');
+  static const bool use_lg3 = ab_env_int("MSDA_HIP_FUSED_LG3", 1) != 0;
   // encoder-shaped calls: the LDS-window kernel with the prologue folded in while the samples are local (variant 0
   // follows the locality report like the operator does; variants 9 / 7 pin the window / the gather kernel)
   if (variant != kAuto) drop_call_context();

@@ -52,11 +52,6 @@
 namespace msda {
 namespace {
 
-// A/B switch (tools/abl_build.sh): 1 = window-DMA offsets from scalar chunk bases + two per-lane constants (round 4), 0 = per-lane
-// (row, column, inside-the-image, pixel, offset) arithmetic for every DMA instruction.  profiles/r04_forward_instruction_cuts.txt
-#ifndef MSDA_WIN_FASTDMA
-#define MSDA_WIN_FASTDMA 1
-#endif
 constexpr int kT = 512, kWaves = kT / 64, kQuads = kT / 4;
 // auto dispatch (win_forward_auto): the window kernel is used while the last reported far fraction is at most this, and the
 // statistic is refreshed every kReprobe-th call otherwise.  Measured on model-like patterns of growing spread (round 4,
@@ -393,7 +388,6 @@ __device__ __forceinline__ void win_body(const float* __restrict__ value, const 
         // values do not fit the scalar registers and come back as v_readlane of spilled SGPRs, a vector instruction each
         int wvs = wv;
         asm volatile("" : "+s"(wvs));
-#if MSDA_WIN_FASTDMA
         // Round 4: the byte offset of a lane in a DMA instruction is  (scalar base of the chunk)  +  (slot of the lane within
         // the chunk) * pitch + piece, and a chunk of 8 consecutive window slots spans at most two window rows -- so the 17
         // vector instructions of per-lane (row, column, inside-the-image, pixel, offset) arithmetic per DMA instruction become
@@ -402,14 +396,12 @@ __device__ __forceinline__ void win_body(const float* __restrict__ value, const 
         uint32_t vsub = (uint32_t)sub;
         asm volatile("" : "+v"(vsub));                        // a VGPR: the selects below compare it with scalars
         const uint32_t vlane = mad_u24(vsub, pixB, chunk);
-#endif
         auto stage_level = [&](auto ltag) __attribute__((always_inline)) {
           constexpr int LV = decltype(ltag)::value;
           constexpr int WW = kWW[LV], C0 = kBase[LV] / 8, C1 = kBase[LV + 1] / 8;
           constexpr int kSteps = (C1 - C0 + kWaves - 1) / kWaves;
           const int Hs = lvH[LV], Ws = lvW[LV], xS = ogx[LV] + lvS[LV], oy = ogy[LV], ox = ogx[LV];
           int i = C0 + ((wvs - C0) & (kWaves - 1));              // this wave's first chunk of the level
-#if MSDA_WIN_FASTDMA
           if (Ws + 2 >= WW) {                                    // at most ONE window column outside the image on either side
             // window column 0 is x = -1 / column WW - 1 is x = W  (an int, not a bool: the compiler keeps booleans of uniform
             // compares as lane masks and re-materialises them through a VGPR at every use)
@@ -439,7 +431,7 @@ __device__ __forceinline__ void win_body(const float* __restrict__ value, const 
             }
             return;
           }
-#endif
+          // (levels narrower than their window: per-lane row / column / inside-the-image arithmetic for every DMA instruction)
           int subv = sub;
           asm volatile("" : "+v"(subv));                      // opaque: the level's start is computed HERE
           const int rel = 8 * (i - C0) + subv;                  // slot of this lane in the level's window
@@ -573,9 +565,6 @@ __device__ __forceinline__ void win_body(const float* __restrict__ value, const 
           asm volatile("" : "+v"(accA), "+v"(accB));
         };
         Far f0;
-#ifdef MSDA_WIN_NOFAR   // timing experiment only: far samples are dropped (1: everywhere, 2: in round 0, 3: in the later rounds)
-        if (MSDA_WIN_NOFAR == 1 || (MSDA_WIN_NOFAR == 2 && rnd == 0) || (MSDA_WIN_NOFAR == 3 && rnd != 0)) fm = 0;
-#endif
         // round 0: the loads of the FIRST far step are issued ahead of the window DMA and consumed behind it (they do not
         // queue behind the CU's whole staging burst, and the wait for them is an exact vmcnt: everything younger is the
         // fixed number of DMA instructions); the barrier follows, further far steps run after it
@@ -976,7 +965,7 @@ bool begin_stat_launch(LocalityArgs* la, hipEvent_t* ev) {
 // call with fewer items than that, or MSDA_WIN_PERSIST=0 -- is ceil(S / 128) per image, all the host knows: at least the tile
 // count of any pyramid whose level 0 holds <= ~3/4 of the pixels; surplus workgroups exit at once.
 static int win_workgroups_per_head(const Dims& d) {
-  static const bool oneshot = std::getenv("MSDA_WIN_PERSIST") && std::getenv("MSDA_WIN_PERSIST")[0] == '0';   // A/B switch
+  static const bool oneshot = ab_env_int("MSDA_WIN_PERSIST", 1) == 0;   // A/B switch
   static const int cus = [] {
     int dev = 0, n = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
@@ -991,7 +980,7 @@ static int win_workgroups_per_head(const Dims& d) {
 
 int launch_forward_win(const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc, const float* attn,
                        const Dims& d, float* out, hipStream_t stream) {
-  static const bool nt = std::getenv("MSDA_WIN_NT") && std::getenv("MSDA_WIN_NT")[0] == '1';   // A/B switch
+  static const bool nt = ab_env_int("MSDA_WIN_NT", 0) == 1;   // A/B switch
   static std::atomic<uint64_t> lds_opted_in[3] = {{0}, {0}, {0}};
   LocalityArgs la;
   hipEvent_t ev = nullptr;

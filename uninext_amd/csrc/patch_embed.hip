@@ -394,7 +394,7 @@ static int launch_packed_bm(const float* x, const uint32_t* packed, const float*
 template <int KS>
 static int launch_packed(const float* x, const uint32_t* packed, const float* bias, const Geom& g, int channels_last,
                          float* out, hipStream_t stream) {
-  static const int forced = std::getenv("PATCH_EMBED_BM") ? std::atoi(std::getenv("PATCH_EMBED_BM")) : 0;
+  static const int forced = msda::ab_env_int("PATCH_EMBED_BM", 0);
   if (forced == 128) return launch_packed_bm<KS, 128>(x, packed, bias, g, channels_last, out, stream);
   return launch_packed_bm<KS, 64>(x, packed, bias, g, channels_last, out, stream);
 }
@@ -417,7 +417,7 @@ template <int KS>
 static int launch(const float* x, const float* w, const float* bias, const Geom& g, int channels_last, float* out,
                   hipStream_t stream) {
   auto tiles = [&](int bm, int bn) { return (long long)((g.Mtot + bm - 1) / bm) * ((g.E + bn - 1) / bn); };
-  static const int forced = std::getenv("PATCH_EMBED_TILE") ? std::atoi(std::getenv("PATCH_EMBED_TILE")) : 0;
+  static const int forced = msda::ab_env_int("PATCH_EMBED_TILE", 0);
   int cfg = g.K <= 64 ? 2 : (tiles(128, 128) >= 256 ? 0 : 1);
   if (forced >= 1 && forced <= 3) cfg = forced - 1;
   if (cfg == 0) return launch_tile<KS, 128, 128>(x, w, bias, g, channels_last, out, stream);

@@ -169,39 +169,23 @@ def _packed_weight(conv):
     return packed_weight(conv, _ext.conv3x3_pack_weight)
 
 
-def _pack_exact(weight):
-    return _ext.conv3x3_pack_weight(weight, exact=True)
-
-
-def _packed_weight_exact(conv):
-    """fp32 re-ordered copy of conv.weight for the exact halo kernel, cached like the split-bf16 one (its own cache slot)."""
-    return packed_weight(conv, _pack_exact, slot="_msda_packed_exact")
-
-
-EXACT_CONV_IMPL = os.environ.get("UNINEXT_AMD_EXACT_CONV", "library")   # "library" | "mfma"
-
-
-def conv3x3_relu(x, conv, exact=True, exact_impl=None):
+def conv3x3_relu(x, conv, exact=True):
     """`F.relu(conv(x))` for a 3x3 / padding 1 nn.Conv2d.
-    exact=True (default): fp32 arithmetic as in the reference -- through the PyTorch-ROCm / MIOpen convolution ("library", the
-    default: ~750 us for the head's module forward at bs 2) or this library's exact-fp32 MFMA kernels (exact_impl="mfma" or env
-    UNINEXT_AMD_EXACT_CONV=mfma): conv3x3_hip_packed_exact_f32 -- halo tiles, one fixed-order fp32 FMA chain per output, bitwise
-    repeatable; ~930 us for the module, faster than MIOpen on the 256 -> 256 layer at 50 x 84 and behind it elsewhere
-    (profiles/r04_conv3x3_exact.txt) -- or conv3x3_hip_f32 for layers it does not take (input channels not a multiple of 16,
-    fewer than 32 outputs).  exact=False opts into the split-bf16 MFMA kernels of include/conv3x3_hip.h from cached packed
-    weights (~390 us, ~2e-5 of the output scale, inside the 1e-4 parity bound).  Training, CPU, other dtypes or geometries:
-    PyTorch."""
-    needs_grad = torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad)
-    if exact and (exact_impl or EXACT_CONV_IMPL) != "mfma":
+    exact=True (default): fp32 arithmetic as in the reference, through the PyTorch-ROCm / MIOpen convolution (~750 us for the
+    head's module forward at bs 2).  This library's own exact-fp32 MFMA convolution (conv3x3_hip_packed_exact_f32,
+    include/conv3x3_hip.h) was WITHDRAWN from the module in round 5: it loses to MIOpen on four of the head's five layers
+    (929-939 us for the module, profiles/r04_conv3x3_exact.txt) -- it stays in the C ABI as a tested entry point.
+    exact=False opts into the split-bf16 MFMA kernels of include/conv3x3_hip.h from cached packed weights (~390 us, ~2e-5 of
+    the output scale, inside the 1e-4 parity bound); layers they do not take (input channels not a multiple of 16) go
+    through conv3x3_hip_f32.  Training, CPU, other dtypes or geometries: PyTorch."""
+    if exact:
         return F.relu(conv(x))
+    needs_grad = torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad)
     if (not needs_grad and tuple(conv.kernel_size) == (3, 3) and tuple(conv.padding) == (1, 1)
             and tuple(conv.stride) == (1, 1) and tuple(conv.dilation) == (1, 1) and conv.groups == 1
             and _ext.conv3x3_supported(x, conv.weight)):
-        if not exact and conv.weight.shape[1] % 16 == 0:
+        if conv.weight.shape[1] % 16 == 0:
             return _ext.conv3x3_packed_forward(x.contiguous(), _packed_weight(conv), conv.weight.shape[0], conv.bias, relu=True)
-        if exact and conv.weight.shape[1] % 16 == 0 and conv.weight.shape[0] >= 32:
-            return _ext.conv3x3_packed_forward(x.contiguous(), _packed_weight_exact(conv), conv.weight.shape[0], conv.bias,
-                                               relu=True, exact=True)
         return _ext.conv3x3_forward(x.contiguous(), conv.weight.contiguous(), conv.bias, relu=True)
     return F.relu(conv(x))
 
@@ -212,11 +196,9 @@ class MaskHeadSmallConv(CachedModuleMixin, torch.nn.Module):
     `F.relu(self.layN(...))` steps go through conv3x3_relu.  `use_raft` is not covered (False in every shipped
     config, uninext/config.py:178)."""
 
-    # True (default): the reference's fp32 arithmetic (MIOpen convolutions, or this library's exact-fp32 MFMA kernel with
-    # exact_impl = "mfma"); False -- or env UNINEXT_AMD_SPLIT_BF16=1 -- opts into the split-bf16 MFMA kernels (3 of 4 partial
-    # products, ~2e-5 of the output scale; the fast ones, see DESIGN.md)
+    # True (default): the reference's fp32 arithmetic (MIOpen convolutions); False -- or env UNINEXT_AMD_SPLIT_BF16=1 -- opts
+    # into the split-bf16 MFMA kernels (3 of 4 partial products, ~2e-5 of the output scale; the fast ones, see DESIGN.md)
     exact_fp32 = os.environ.get("UNINEXT_AMD_SPLIT_BF16", "0") != "1"
-    exact_impl = None      # None: module-level EXACT_CONV_IMPL ("library"); "mfma": conv3x3_hip_packed_exact_f32 / conv3x3_hip_f32
 
     def __init__(self, dim, fpn_dims, context_dim, use_raft=False, up_rate=4):
         super().__init__()
@@ -257,9 +239,9 @@ class MaskHeadSmallConv(CachedModuleMixin, torch.nn.Module):
 
     def forward(self, x, fpns):
         f = fpns if fpns is not None else (None, None, None)
-        e, i = self.exact_fp32, self.exact_impl
-        fused = conv3x3_relu(self._merge(x[-1], getattr(self, "adapter1", None), f[0], None), self.lay3, e, i)
-        fused = conv3x3_relu(self._merge(x[-2], getattr(self, "adapter2", None), f[1], fused), self.lay4, e, i)
-        fused_fpn = conv3x3_relu(self._merge(x[-3], getattr(self, "adapter3", None), f[2], fused), self.jia_dcn, e, i)
-        fused = conv3x3_relu(fused_fpn, self.lay1, e, i)
-        return conv3x3_relu(fused, self.lay2, e, i)
+        e = self.exact_fp32
+        fused = conv3x3_relu(self._merge(x[-1], getattr(self, "adapter1", None), f[0], None), self.lay3, e)
+        fused = conv3x3_relu(self._merge(x[-2], getattr(self, "adapter2", None), f[1], fused), self.lay4, e)
+        fused_fpn = conv3x3_relu(self._merge(x[-3], getattr(self, "adapter3", None), f[2], fused), self.jia_dcn, e)
+        fused = conv3x3_relu(fused_fpn, self.lay1, e)
+        return conv3x3_relu(fused, self.lay2, e)
