@@ -106,6 +106,7 @@ def test_full_size_r50_head(dev):
 
 
 def test_stream_graph_and_autograd_route(dev):
+    from uninext_amd import ext
     from uninext_amd.mask_head import conv3x3_relu
     conv = torch.nn.Conv2d(16, 24, 3, padding=1).to(dev)
     x = torch.randn(2, 16, 11, 13, device=dev)
@@ -113,7 +114,7 @@ def test_stream_graph_and_autograd_route(dev):
         want = torch.relu(conv(x))
         s = torch.cuda.Stream()
         with torch.cuda.stream(s):
-            a = conv3x3_relu(x, conv, True, "mfma")       # this library's exact-fp32 kernel (the default exact route is MIOpen)
+            a = ext.conv3x3_forward(x, conv.weight, conv.bias, relu=True)   # this library's exact-fp32 kernel, on a side stream
         s.synchronize()
         assert float((a - want).abs().max()) < 1e-4
         graph = torch.cuda.CUDAGraph()

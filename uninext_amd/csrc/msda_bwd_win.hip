@@ -30,10 +30,12 @@
 //                that is also inside B's window of its level (same window column origin, rows shifted by dy) is MOVED up dy
 //                rows in LDS and keeps collecting; only the rows that leave go to grad_value, as ONE full-line float atomic per
 //                touched pixel.  Round 4 flushed every window whole: 592 slots per item for 170 pixels' worth of queries, 250 MB
-//                written per launch for 114 MB of algorithmic output; a carried transition flushes 260.  The fixed-point scale
-//                is shared along such a chain of items: it comes from the SUM of their bounds (carried values are shifted
-//                right when it grows), and the chain is cut -- everything flushed -- when that sum exceeds 8 x the new tile's
-//                own bound (include/msda_hip.h: steps of <= 2^-19 of the largest upstream gradient of the chain's tiles).
+//                written per launch for 114 MB of algorithmic output; a carried transition flushes 260.  Every item keeps its OWN
+//                fixed-point scale (from its own bound, as before): a carried value is re-expressed in the new item's scale
+//                when it is moved -- shifted left (exact) or right (rounded once) -- and an accumulator that would not leave the
+//                new item its full 2^30 of head room (|v| >= 2^30 after the shift: never seen, the bound is that pessimistic) is
+//                flushed instead of carried.  The LDS half of the transition runs in front of barrier #3, its float atomics
+//                BEHIND it (from registers): their acknowledgements drain under the pass instead of under the wait for the DMA.
 //
 // Per-sample arithmetic (cuh:113-158, refactored as in msda_bwd_tiled): with F / S the first / second pixel of a corner
 // row in this quad's read order and u the bilinear weight of S:
@@ -63,12 +65,10 @@ struct Meta {
   int lvl[4][4];                                                // per level: H, W, first pixel, -
   unsigned gmax_bits, amax_bits, pad0, pad1;                    // per tile: max |grad_out|, max_pair sum |attn| (float bits)
   // what is still in the accumulator windows: the last item's window origins, scale exponent, chain bound, and whether it used them
-  int org[4][2];
-  int prevE;
-  unsigned cum_bits;
-  int prev_lds, pad2;
+  // (two copies, by item parity: an item reads its predecessor's copy in its head AND behind barrier #3, and writes its own)
+  int org[2][4][2];
+  int stE[2], stLds[2];
 };
-constexpr int kChainHeadroom = 8;                               // a chain of carried items ends when the sum of its bounds exceeds this x the new tile's
 constexpr int kMetaOff = kAccOff + kSlots * 128;
 constexpr int kLdsBytes = kMetaOff + ((sizeof(Meta) + 15) / 16) * 16;
 static_assert(kLdsBytes <= 160 * 1024, "one workgroup per CU");
@@ -193,7 +193,7 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
   }
   for (int o = tid * 16; o < kSlots * 128; o += kT * 16) *reinterpret_cast<f32x4*>(smem + kAccOff + o) = f32x4{0.f, 0.f, 0.f, 0.f};
   if (tid >= 640 && tid < 656) (&mt.sum[0][0])[tid - 640] = 0;
-  if (tid == 656) { mt.gmax_bits = 0u; mt.amax_bits = 0u; mt.prev_lds = 0; mt.prevE = 0; mt.cum_bits = 0u; }   // (pad0: written by the fetch of every item's first pass before it is read)
+  if (tid == 656) { mt.gmax_bits = 0u; mt.amax_bits = 0u; mt.stLds[0] = 0; mt.stLds[1] = 0; mt.stE[0] = 0; mt.stE[1] = 0; }   // (pad0: written by the fetch of every item's first pass before it is read)
 
   const uint32_t pixB = (uint32_t)M * 128u;                // bytes from a pixel of head m to the next one
   const uint32_t hoff = (uint32_t)m * 128u;
@@ -259,9 +259,84 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
       };
 
       BW_STAMP(3);                                           // query decoded, loads issued
-      int pgx[4] = {0, 0, 0, 0}, pgy[4] = {0, 0, 0, 0}, prevE = 0, E = 0, carry_mask = 0;   // (pass 0 only)
-      float cum = 0.f;
-      bool prev_lds = false;
+      int E = 0, carry_mask = 0;                             // (pass 0 only) this item's scale exponent; levels that carry
+      int xa[kWH[0]], xb[kWH[1]], xc[kWH[2]];                // what leaves the accumulators in this step's transition (three columns per half wave)
+      // ---- the transition of the previous item's accumulators (they are still in LDS).  LDS half (`move_column`, in front of
+      // barrier #3, under the window DMA): rows that are also in this item's window move up, re-expressed in this item's scale; the
+      // rows that leave are read into registers and cleared.  Memory half (`flush_column`, behind barrier #3): their float atomics.
+      // What the previous item's accumulators are addressed and scaled by is read from Meta where it is needed (uniform values
+      // that would otherwise sit in ~12 vector registers from the item's head to behind barrier #3).
+      struct Prev { int gx[4], gy[4], E; bool lds; float inv; char* gv; };
+      const int ch = tid & 31, hw2 = tid >> 5;               // channel; half wave 0..21
+      const int pbuf = (item - 1 - first) & 1;               // parity of the previous item (the first item finds stLds == 0)
+      auto load_prev = [&]() __attribute__((always_inline)) {
+        Prev P;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) { P.gx[l] = mt.org[pbuf][l][0]; P.gy[l] = mt.org[pbuf][l][1]; }
+        P.E = mt.stE[pbuf];
+        P.lds = mt.stLds[pbuf] != 0;
+        P.inv = ldexpf(1.f, -P.E);
+        const int bA = to_sgpr((int)(((float)max(item - 1, 0) + 0.5f) * __builtin_amdgcn_rcpf((float)ntiles)));
+        P.gv = reinterpret_cast<char*>(grad_value + (int64_t)bA * d.S * M * 32) + hoff + ch * 4;
+        return P;
+      };
+      auto pixel_A = [&](const Prev& P, auto ltag, int c, int r, bool& inside) __attribute__((always_inline)) {   // byte offset of slot (r, c) of the PREVIOUS item's window
+        constexpr int LV = decltype(ltag)::value;
+        const int xA = P.gx[LV] + c, yA = P.gy[LV] + r;
+        inside = (unsigned)xA < (unsigned)lvW[LV] && (unsigned)yA < (unsigned)lvH[LV];
+        return (uint32_t)(lvS[LV] + yA * lvW[LV] + xA) * pixB;
+      };
+      auto move_column = [&](const Prev& P, auto ltag, int c, auto& xs) __attribute__((always_inline)) {
+        constexpr int LV = decltype(ltag)::value, WH = kWH[LV];
+        constexpr uint32_t kRowB = (uint32_t)kWW[LV] * 128u;
+        const int sh = P.E - E;                                // carried values: >> sh (rounded) or << -sh
+        const bool carry = ((carry_mask >> LV) & 1) != 0;
+        const int dy = carry ? ogy[LV] - P.gy[LV] : WH;       // rows [0, dy) leave, row r + dy becomes row r
+        const uint32_t a0 = smem_base + (uint32_t)kAccOff + (uint32_t)(kBase[LV] + c) * 128u + (uint32_t)ch * 4u;
+        int y[WH];
+#pragma unroll
+        for (int r = 0; r < WH; ++r) xs[r] = *reinterpret_cast<lds_int_ptr>((uintptr_t)(a0 + (uint32_t)r * kRowB));
+#pragma unroll
+        for (int r = 0; r < WH; ++r)
+          y[r] = r + dy < WH ? *reinterpret_cast<lds_int_ptr>((uintptr_t)(a0 + (uint32_t)(r + dy) * kRowB)) : 0;
+#pragma unroll
+        for (int r = 0; r < WH; ++r) {
+          const int v = y[r];
+          // this item may add up to 2^30 to the slot: a carried value has to stay below 2^30 in the new scale
+          const int lim = sh >= 0 ? 0x40000000 : (sh > -30 ? 0x40000000 >> -sh : 0);
+          int nv;
+          if ((v < 0 ? -v : v) < lim || v == 0) {
+            nv = sh >= 0 ? ((sh > 31 ? 0 : (v + (sh > 0 ? 1 << (sh - 1) : 0)) >> min(sh, 31))) : v << min(-sh, 31);
+          } else {                                           // (never observed) does not fit: it leaves with the rows above it
+            bool inside;
+            const uint32_t off = pixel_A(P, ltag, c, r + dy, inside);
+            if (inside) atomic_add(reinterpret_cast<float*>(P.gv + (size_t)off), (float)v * P.inv);
+            nv = 0;
+          }
+          if (nv != xs[r]) *reinterpret_cast<lds_int_ptr>((uintptr_t)(a0 + (uint32_t)r * kRowB)) = nv;
+          if (r >= dy) xs[r] = 0;                            // row r stayed (it was moved or handled above): nothing of it to flush
+        }
+      };
+      auto flush_column = [&](const Prev& P, auto ltag, int c, const auto& xs) __attribute__((always_inline)) {
+        constexpr int LV = decltype(ltag)::value, WH = kWH[LV];
+#pragma unroll
+        for (int r = 0; r < WH; ++r) {
+          bool inside;
+          const uint32_t off = pixel_A(P, ltag, c, r, inside);
+          if (xs[r] != 0 && inside) atomic_add(reinterpret_cast<float*>(P.gv + (size_t)off), (float)xs[r] * P.inv);
+        }
+      };
+      using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>;
+      using J2 = std::integral_constant<int, 2>; using J3 = std::integral_constant<int, 3>;
+      // 22 half waves: column hw2 of the level-0 window; column hw2 of the 14 + 8 columns of levels 1 / 2's first eight; the last
+      // two columns of level 2 and the eight of level 3 on the first ten half waves
+      const int jb = hw2, jc = hw2 + kT / 32;
+      static_assert(kT / 32 == kWW[0] && kWW[1] + 8 == kT / 32 && kWW[2] == 10 && kWW[3] == 8, "column tasks of the transition");
+      auto columns = [&](const Prev& P, auto&& fn) __attribute__((always_inline)) {
+        fn(P, J0{}, hw2, xa);
+        if (jb < kWW[1]) fn(P, J1{}, jb, xb); else fn(P, J2{}, jb - kWW[1], xb);
+        if (jc < kWW[1] + kWW[2]) fn(P, J2{}, jc - kWW[1], xc); else if (jc < kWW[1] + kWW[2] + kWW[3]) fn(P, J3{}, jc - kWW[1] - kWW[2], xc);
+      };
       if (pass == 0 && !tail) {
         // ---- fixed-point scale: every slot receives at most (#pairs of the tile) x max |grad_out| x max_pair sum |attn| ----
         {
@@ -306,12 +381,6 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
         BW_STAMP(4);                                         // loads arrived; maxima and placement sums added
         lds_barrier();                                       // #2: sums and scale words complete
         BW_STAMP(5);
-        // ---- the item before this one: its origins and scale address what is still in the accumulators ----
-#pragma unroll
-        for (int l = 0; l < 4; ++l) { pgx[l] = mt.org[l][0]; pgy[l] = mt.org[l][1]; }
-        prevE = mt.prevE;
-        prev_lds = mt.prev_lds != 0;
-        cum = __uint_as_float(mt.cum_bits);
         int myOx, myOy;
         {
           const int4 sm = *reinterpret_cast<const int4*>(&mt.sum[k][0]);
@@ -328,32 +397,27 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
           ogx[l] = __builtin_amdgcn_readlane(myOx, l);
           ogy[l] = __builtin_amdgcn_readlane(myOy, l);
         }
-        // ---- which levels carry their accumulators over from the previous item, and the scale of this one ----------------------
+        // ---- the scale of this item; which levels carry their accumulators over from the previous one -------------------------
         {
           const int npairs = kL0Waves * 16 + (int)mt.pad0;
           const float bound = (float)npairs * __uint_as_float(mt.gmax_bits) * __uint_as_float(mt.amax_bits);
           // false for NaN / Inf, and for tiles of more than 256 pairs (pyramids with a finer level after the first): every
           // sample then takes the float-atomic path (thousands of roundings per pixel at a coarse scale add up past 1e-4)
-          const bool lds_ok = bound < 0x1p120f && npairs <= 256;   // (>= 2^120: the clamped exponent below could not scale it into int32)
-          int geo = 0;                                            // levels whose window kept its columns and moved down by < its height
-#pragma unroll
-          for (int l = 0; l < 4; ++l)
-            geo |= (ogx[l] == pgx[l] && (unsigned)(ogy[l] - pgy[l]) < (unsigned)kWH[l]) ? (1 << l) : 0;
-          // the chain goes on while its scale stays within kChainHeadroom x of what this tile alone would get (precision) and
-          // this tile's bound is not astronomically larger than the chain's (the carried values are shifted right by < 24 bits)
-          const bool chain = prev_lds && lds_ok && geo != 0 && bound > 0.f && cum <= (float)(kChainHeadroom - 1) * bound &&
-                             bound <= 0x1p20f * cum && cum + bound < 0x1p120f;
-          const float cumB = chain ? cum + bound : bound;
+          use_lds = bound < 0x1p120f && npairs <= 256;   // (>= 2^120: the clamped exponent below could not scale it into int32)
           int e = 0;
-          if (lds_ok && cumB > 0.f) {
-            (void)frexpf(cumB, &e);                          // cumB < 2^e: what a slot can hold of the chain stays below 2^30
+          if (use_lds && bound > 0.f) {
+            (void)frexpf(bound, &e);                         // bound < 2^e: what this item adds to a slot stays below 2^30
             e = max(-90, min(90, 30 - e));
           }
-          carry_mask = chain ? geo : 0;
           E = e;
-          cum = cumB;
-          use_lds = lds_ok;
           scale = ldexpf(1.f, E);
+          // a level carries when its window kept its columns and moved down by less than its height -- in the SAME image (a level
+          // smaller than its window has the same clamped origin in every tile of every image) -- and both items use the LDS
+          if (mt.stLds[pbuf] != 0 && use_lds && itemc - b * ntiles > 0) {
+#pragma unroll
+            for (int l = 0; l < 4; ++l)
+              carry_mask |= (ogx[l] == mt.org[pbuf][l][0] && (unsigned)(ogy[l] - mt.org[pbuf][l][1]) < (unsigned)kWH[l]) ? (1 << l) : 0;
+          }
         }
         // ---- stage the four value windows: LDS-DMA, one instruction = 8 consecutive slots (1 KB) of ONE level per wave ----
         {
@@ -392,63 +456,19 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
         }
       }
 
+      BW_STAMP(2);                                           // origins, window DMA issued
       if (pass == 0) {
-        if (tail) {                                          // the step behind the last item: everything leaves
-#pragma unroll
-          for (int l = 0; l < 4; ++l) { pgx[l] = mt.org[l][0]; pgy[l] = mt.org[l][1]; }
-          prevE = mt.prevE;
-          prev_lds = mt.prev_lds != 0;
-        }
-        // ---- transition: the previous item's accumulators.  Rows that are also in this item's window move up (and are rescaled
-        // when the chain's scale grew); the rows that leave go to grad_value.  The window DMA issued above travels meanwhile. ----
-        if (prev_lds) {
-          const int ch = tid & 31, hw2 = tid >> 5;             // channel; half wave 0..21
-          const int sh = carry_mask ? prevE - E : 0;           // >= 0: the chain's bound only grows
-          const int rnd = sh > 0 ? 1 << (sh - 1) : 0;
-          const float invA = ldexpf(1.f, -prevE);
-          const int bA = to_sgpr((int)(((float)max(item - 1, 0) + 0.5f) * __builtin_amdgcn_rcpf((float)ntiles)));
-          char* const gvA = reinterpret_cast<char*>(grad_value + (int64_t)bA * d.S * M * 32) + hoff + ch * 4;
-          auto column = [&](auto ltag, int c) __attribute__((always_inline)) {
-            constexpr int LV = decltype(ltag)::value, WH = kWH[LV];
-            constexpr uint32_t kRowB = (uint32_t)kWW[LV] * 128u;
-            const bool carry = ((carry_mask >> LV) & 1) != 0;
-            const int dy = carry ? ogy[LV] - pgy[LV] : WH;      // rows [0, dy) leave, row r + dy becomes row r
-            const uint32_t a0 = smem_base + (uint32_t)kAccOff + (uint32_t)(kBase[LV] + c) * 128u + (uint32_t)ch * 4u;
-            int x[WH], y[WH];
-#pragma unroll
-            for (int r = 0; r < WH; ++r) x[r] = *reinterpret_cast<lds_int_ptr>((uintptr_t)(a0 + (uint32_t)r * kRowB));
-#pragma unroll
-            for (int r = 0; r < WH; ++r)
-              y[r] = r + dy < WH ? *reinterpret_cast<lds_int_ptr>((uintptr_t)(a0 + (uint32_t)(r + dy) * kRowB)) : 0;
-            const int xA = pgx[LV] + c;
-            const bool xin = (unsigned)xA < (unsigned)lvW[LV];
-            const uint32_t col_off = (uint32_t)(lvS[LV] + xA) * pixB;
-#pragma unroll
-            for (int r = 0; r < WH; ++r) {
-              const int yA = pgy[LV] + r;
-              if (r < dy && x[r] != 0 && xin && (unsigned)yA < (unsigned)lvH[LV])
-                atomic_add(reinterpret_cast<float*>(gvA + (size_t)(col_off + (uint32_t)(yA * lvW[LV]) * pixB)), (float)x[r] * invA);
-            }
-#pragma unroll
-            for (int r = 0; r < WH; ++r) {
-              const int nv = (y[r] + rnd) >> sh;
-              if (nv != x[r]) *reinterpret_cast<lds_int_ptr>((uintptr_t)(a0 + (uint32_t)r * kRowB)) = nv;
-            }
-          };
-          using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>;
-          using J2 = std::integral_constant<int, 2>; using J3 = std::integral_constant<int, 3>;
-          column(J0{}, hw2);                                   // 22 half waves = the 22 columns of the level-0 window
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {                        // the 14 + 10 + 8 columns of the other windows
-            const int j = hw2 + t * (kT / 32);
-            if (j < kWW[1]) column(J1{}, j);
-            else if (j < kWW[1] + kWW[2]) column(J2{}, j - kWW[1]);
-            else if (j < kWW[1] + kWW[2] + kWW[3]) column(J3{}, j - kWW[1] - kWW[2]);
+        // ---- transition, LDS half (in the tail step -- behind the last item -- everything leaves, both halves at once) -------------
+        {
+          const Prev P = load_prev();
+          if (P.lds) columns(P, move_column);
+          if (tail) {
+            if (P.lds) columns(P, flush_column);
+            break;
           }
         }
-        if (tail) break;
       }
-      BW_STAMP(6);                                           // origins, window DMA issued
+      BW_STAMP(6);                                           // transition: accumulators moved
       // ---- sample coordinates; near (all four corners inside the level's window or outside the image) or far? -----------
       v2f xy[4];
       uint32_t inb = 0, nb = 0;
@@ -475,8 +495,15 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
         if (tid == 16) { mt.gmax_bits = 0u; mt.amax_bits = 0u; }   // (pad0 is rewritten for every item, before barrier #4 of the one before)
         // ... and what the NEXT step's transition needs to know about this item's accumulators (everybody has read the previous
         // item's in front of the transition above)
-        if (tid < 4) { mt.org[tid][0] = sel4(k0, k1, ogx[0], ogx[1], ogx[2], ogx[3]); mt.org[tid][1] = sel4(k0, k1, ogy[0], ogy[1], ogy[2], ogy[3]); }
-        if (tid == 17) { mt.prevE = E; mt.cum_bits = __float_as_uint(cum); mt.prev_lds = use_lds ? 1 : 0; }
+        if (tid < 4) { mt.org[pbuf ^ 1][tid][0] = sel4(k0, k1, ogx[0], ogx[1], ogx[2], ogx[3]); mt.org[pbuf ^ 1][tid][1] = sel4(k0, k1, ogy[0], ogy[1], ogy[2], ogy[3]); }
+        if (tid == 17) { mt.stE[pbuf ^ 1] = E; mt.stLds[pbuf ^ 1] = use_lds ? 1 : 0; }
+        // ---- transition, memory half: what left the accumulators goes to grad_value, one full-line float atomic per touched pixel;
+        // nothing waits for these until the far samples behind the pass
+        {
+          const Prev P = load_prev();
+          if (P.lds) columns(P, flush_column);
+        }
+        BW_STAMP(15);                                          // transition: atomics issued
       }
 
       if (!l0) __builtin_amdgcn_s_setprio(2);                  // the three youngest waves of the workgroup would finish the pass last

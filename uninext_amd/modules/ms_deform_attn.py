@@ -43,7 +43,7 @@ class MSDeformAttn(CachedModuleMixin, nn.Module):
     fuse_prologue = os.environ.get("UNINEXT_AMD_NO_FUSED", "0") != "1"
     # training: MSDeformAttnFusedFunction (fused forward from the raw Linear outputs; backward recomputes the locations / weights
     # and runs the operator's backward kernels) instead of the PyTorch prologue + MSDeformAttnFunction
-    fuse_training_prologue = os.environ.get("UNINEXT_AMD_NO_FUSED_TRAINING", "0") != "1"
+    fuse_training_prologue = True          # (class attribute; UNINEXT_AMD_NO_FUSED=1 switches both fusions off)
     fast_linear = os.environ.get("UNINEXT_AMD_SPLIT_BF16", "0") == "1"   # opt-in: split-bf16 projections at inference
 
     def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4):
