@@ -206,7 +206,7 @@ def test_reference_style_layers_without_a_call_site_get_one_each(dev, api):
 
     flav = ["model"] * 4 + ["uniform"] * 2
     xs = [_inputs(f, workloads.R50_LEVELS_INFER, 81 + i, dev) for i, f in enumerate(flav)]
-    ext.reset_auto_sites()
+    ext.reset_auto_sites(forget_history=True)        # (earlier tests made plain calls: the derived slots are process-wide)
     for p in range(5):
         shapes, lsi = xs[0]["shapes"].clone(), xs[0]["lsi"].clone()          # one tensor object per pass, shared by the layers
         seen["fwd"].clear(); seen["bwd"].clear()

@@ -14,7 +14,7 @@ EXPORTS = (
     "msda_hip_forward_fused_f32", "msda_hip_forward_fused_hm_f32",
     "msda_host_forward_f32", "msda_host_forward_f64", "msda_host_backward_f32", "msda_host_backward_f64",
     "msda_hip_set_variant", "msda_hip_get_variant", "msda_hip_variant_name", "msda_hip_last_kernel",
-    "msda_hip_forward_locality", "msda_hip_set_call_context",
+    "msda_hip_forward_locality", "msda_hip_set_call_context", "msda_hip_reset_call_site",
     "msda_hip_backward_workspace_bytes", "msda_hip_backward_ws_f32", "msda_host_last_num_threads",
     "msda_hip_prologue_f32", "msda_hip_prologue_backward_f32",
 )
@@ -126,6 +126,7 @@ def load():
     lib.msda_hip_variant_name.argtypes, lib.msda_hip_variant_name.restype = [i, i], s
     lib.msda_hip_last_kernel.argtypes, lib.msda_hip_last_kernel.restype = [i], s
     lib.msda_hip_forward_locality.argtypes, lib.msda_hip_forward_locality.restype = [ctypes.POINTER(ctypes.c_double)], i
+    lib.msda_hip_reset_call_site.argtypes, lib.msda_hip_reset_call_site.restype = [i], None
     lib.msda_hip_set_call_context.argtypes, lib.msda_hip_set_call_context.restype = [i, ctypes.c_uint], None
     got = lib.msda_hip_abi_version()
     if got != ABI_VERSION:

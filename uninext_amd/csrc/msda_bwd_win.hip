@@ -291,30 +291,33 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
         constexpr uint32_t kRowB = (uint32_t)kWW[LV] * 128u;
         const int sh = P.E - E;                                // carried values: >> sh (rounded) or << -sh
         const bool carry = ((carry_mask >> LV) & 1) != 0;
-        const int dy = carry ? ogy[LV] - P.gy[LV] : WH;       // rows [0, dy) leave, row r + dy becomes row r
+        const int dy = carry ? ogy[LV] - P.gy[LV] : WH;       // rows [0, dy) leave, row r becomes row r - dy (wave-uniform)
         const uint32_t a0 = smem_base + (uint32_t)kAccOff + (uint32_t)(kBase[LV] + c) * 128u + (uint32_t)ch * 4u;
-        int y[WH];
-#pragma unroll
-        for (int r = 0; r < WH; ++r) xs[r] = *reinterpret_cast<lds_int_ptr>((uintptr_t)(a0 + (uint32_t)r * kRowB));
+        // read AND clear the whole column (one LDS operation per row), then put back what stays, dy rows up
 #pragma unroll
         for (int r = 0; r < WH; ++r)
-          y[r] = r + dy < WH ? *reinterpret_cast<lds_int_ptr>((uintptr_t)(a0 + (uint32_t)(r + dy) * kRowB)) : 0;
+          xs[r] = __hip_atomic_exchange(reinterpret_cast<lds_int_ptr>((uintptr_t)(a0 + (uint32_t)r * kRowB)), 0, __ATOMIC_RELAXED,
+                                        __HIP_MEMORY_SCOPE_WORKGROUP);
+        // this item may add up to 2^30 to a slot: a carried value has to stay below 2^30 in the new scale
+        const int lim = sh >= 0 ? 0x40000000 : (sh > -30 ? 0x40000000 >> -sh : 0);
+        const int rnd = sh > 0 ? 1 << (min(sh, 31) - 1) : 0, shr = min(max(sh, 0), 31), shl = min(max(-sh, 0), 31);
+        const uint32_t up = (uint32_t)dy * kRowB;
 #pragma unroll
         for (int r = 0; r < WH; ++r) {
-          const int v = y[r];
-          // this item may add up to 2^30 to the slot: a carried value has to stay below 2^30 in the new scale
-          const int lim = sh >= 0 ? 0x40000000 : (sh > -30 ? 0x40000000 >> -sh : 0);
-          int nv;
-          if ((v < 0 ? -v : v) < lim || v == 0) {
-            nv = sh >= 0 ? ((sh > 31 ? 0 : (v + (sh > 0 ? 1 << (sh - 1) : 0)) >> min(sh, 31))) : v << min(-sh, 31);
-          } else {                                           // (never observed) does not fit: it leaves with the rows above it
-            bool inside;
-            const uint32_t off = pixel_A(P, ltag, c, r + dy, inside);
-            if (inside) atomic_add(reinterpret_cast<float*>(P.gv + (size_t)off), (float)v * P.inv);
-            nv = 0;
+          if (r >= dy) {                                         // (uniform)
+            const int v = xs[r];
+            if (v != 0) {
+              if (__builtin_expect((v < 0 ? -v : v) < lim, 1)) {
+                const int nv = sh > 31 ? 0 : ((v + rnd) >> shr) << shl;
+                if (nv != 0) *reinterpret_cast<lds_int_ptr>((uintptr_t)(a0 + (uint32_t)r * kRowB - up)) = nv;
+              } else {                                           // (never observed) does not fit: it leaves with the rows above it
+                bool inside;
+                const uint32_t off = pixel_A(P, ltag, c, r, inside);
+                if (inside) atomic_add(reinterpret_cast<float*>(P.gv + (size_t)off), (float)v * P.inv);
+              }
+            }
+            xs[r] = 0;                                           // row r stayed: nothing of it to flush
           }
-          if (nv != xs[r]) *reinterpret_cast<lds_int_ptr>((uintptr_t)(a0 + (uint32_t)r * kRowB)) = nv;
-          if (r >= dy) xs[r] = 0;                            // row r stayed (it was moved or handled above): nothing of it to flush
         }
       };
       auto flush_column = [&](const Prev& P, auto ltag, int c, const auto& xs) __attribute__((always_inline)) {
@@ -488,6 +491,12 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
       if (pass == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of the value windows has landed
         BW_STAMP(8);
+#ifdef BWIN_T2_EARLY
+        {
+          const Prev P = load_prev();
+          if (P.lds) columns(P, flush_column);
+        }
+#endif
         lds_barrier();                                         // #3 ... and everybody else's
         BW_STAMP(9);
         // the next item's placement sums and scale words (everybody has read this item's; the next adds come after barrier #1)
@@ -499,10 +508,12 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
         if (tid == 17) { mt.stE[pbuf ^ 1] = E; mt.stLds[pbuf ^ 1] = use_lds ? 1 : 0; }
         // ---- transition, memory half: what left the accumulators goes to grad_value, one full-line float atomic per touched pixel;
         // nothing waits for these until the far samples behind the pass
+#ifndef BWIN_T2_EARLY
         {
           const Prev P = load_prev();
           if (P.lds) columns(P, flush_column);
         }
+#endif
         BW_STAMP(15);                                          // transition: atomics issued
       }
 

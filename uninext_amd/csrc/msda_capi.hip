@@ -229,6 +229,7 @@ const char* msda_hip_variant_name(int which, int variant) {
 }
 
 int msda_hip_forward_locality(double* far_fraction) { return msda::forward_locality(far_fraction); }
+void msda_hip_reset_call_site(int call_site) { msda::reset_call_site(call_site); }
 
 void msda_hip_set_call_context(int call_site, unsigned flags) { msda::set_call_context(call_site, flags); }
 

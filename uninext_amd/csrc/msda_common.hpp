@@ -170,6 +170,7 @@ int launch_forward_win_fused(const float* value, int head_major, const int64_t* 
                              const float* ref_points, int ref_dim, const float* offsets, const float* logits, const Dims& d,
                              float* out, hipStream_t stream);
 int forward_locality(double* far_fraction);      // reports so far (0: none yet) and the last one's far fraction
+void reset_call_site(int slot);                  // include/msda_hip.h: msda_hip_reset_call_site (< 0: every slot of the current device)
 int launch_forward_win(const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc, const float* attn,
                        const Dims& d, float* out, hipStream_t stream);
 

@@ -858,6 +858,23 @@ int forward_locality(double* far_fraction) {
   return (int)sl.consumed;
 }
 
+// include/msda_hip.h: msda_hip_reset_call_site.  The slot forgets what its calls have reported: its next call is a "first call"
+// again.  Reports of launches still in flight are dropped (their tags lie behind `consumed`).
+void reset_call_site(int slot) {
+  LocalityState* st = locality_state(nullptr);
+  if (!st) return;
+  for (int i = 0; i < kSites; ++i) {
+    if (slot >= 0 && i != slot) continue;
+    Slot& sl = st->slots[i];
+    std::lock_guard<std::mutex> lock(sl.mu);
+    sl.mode = 0;
+    sl.calls = 0;
+    sl.since_probe = 0;
+    sl.far = 0.0;
+    sl.consumed = sl.seq;
+  }
+}
+
 // auto dispatch of the encoder shape: window kernel or msda_fwd_lg3?  Consumes the thread's call context.
 // Backward of an encoder-shaped call made with a call context: msda_bwd_win (value and gradient windows in LDS) when the
 // FORWARD calls of the same site have reported that the samples stay near their tiles, msda_bwd_tiled otherwise.  Nothing

@@ -117,11 +117,18 @@ class _AutoSites:
 _auto = _AutoSites()
 
 
-def reset_auto_sites():
+def reset_auto_sites(forget_history=False):
     """Start a new pass for the derived call sites: the next encoder-shaped call without a call_site() block is layer 0.
-    Only needed by a caller that REUSES one spatial_shapes tensor object across forward passes (the reference rebuilds it)."""
+    Only needed by a caller that REUSES one spatial_shapes tensor object across forward passes (the reference rebuilds it).
+    forget_history=True also clears what the derived slots' earlier calls reported (msda_hip_reset_call_site): for a process
+    that puts another model or checkpoint behind them."""
     with _auto.lock:
         _auto.shapes_ref, _auto.shapes_version, _auto.ordinal = None, -1, 0
+        _auto.by_loc.clear()
+    if forget_history:
+        lib = _lib.load()
+        for site in range(AUTO_SITE_BASE, AUTO_SITE_BASE + AUTO_SITES):
+            lib.msda_hip_reset_call_site(site)
 
 
 def _auto_site(spatial_shapes, sampling_loc, backward=False):
