@@ -88,11 +88,8 @@ int msda_hip_forward_f64(const double* value, const int64_t* spatial_shapes,
  * per-pixel rounding is required, pin the float-atomic kernel: msda_hip_set_variant(1, 1) or MSDA_HIP_BWD_VARIANT=1
  * (msda_bwd_generic, 2.05 ms instead of 0.35 ms per encoder call).  grad_sampling_loc and grad_attn_weight are
  * plain fp32 in every kernel.  tests/test_msda_parity_gpu.py holds the bound on inputs with 8 decades of dynamic range.
- * The same holds for msda_bwd_win (encoder-shaped calls of a call site with near samples); since round 5 it carries the
- * accumulator rows that consecutive tiles of a tile column share from tile to tile in LDS instead of flushing them per tile: a
- * carried partial sum is re-expressed in the next tile's scale (a shift: exact to the left, one more rounding at the NEW
- * tile's step to the right), so a pixel collects at most one extra rounding per tile that touches it (<= 7).  And, on the rows
- * of the two coarsest levels it keeps in LDS, the same holds for msda_bwd_dec -- variant 0 on every other fp32 call with channels 32, 4 levels x 4
+ * The same holds for msda_bwd_win (encoder-shaped calls of a call site with near samples) and, on the rows of the two
+ * coarsest levels it keeps in LDS, for msda_bwd_dec -- variant 0 on every other fp32 call with channels 32, 4 levels x 4
  * points and 64 .. 16384 queries (the decoder): one scale per (image, head, slice of <= min(ceil(num_query / 16), 256)
  * queries) from (4 * queries of the slice) * max|grad_output| * max|attn_weight|, i.e. steps of <= 2^-20 * max|grad_output|
  * of the slice (<= 2^-21 for num_query <= 2048).  The finer levels take float atomics there as in the reference; calls with

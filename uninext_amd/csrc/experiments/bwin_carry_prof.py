@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Phase timeline of msda_bwd_win from in-kernel timestamps (second item of every workgroup).  GPU box only; library built
+"""Phase timeline of msda_bwd_win (round 5: deferred, carried flush) from in-kernel timestamps (second item of every workgroup).  GPU box only; library built
 with -DMSDA_BWIN_PROF (tools/abl_build.sh bwprof msda_bwd_win -DMSDA_BWIN_PROF)."""
 import ctypes, os, sys
 import numpy as np
@@ -7,9 +7,10 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from uninext_amd import _lib, ext, workloads  # noqa: E402
-NAMES = {(0, 1): "barrier #1", (1, 4): "prefetched loads arrive, maxima, placement sums",
-         (4, 5): "barrier #2", (5, 6): "scale, origins, DMA issue", (6, 7): "classify", (7, 8): "own DMA landed", (8, 9): "barrier #3",
-         (9, 10): "pass (gather, gradients, scatter)", (10, 11): "far samples, stores of grad_loc / grad_attn", (11, 14): "next item: decode + issue loads", (14, 12): "barrier #4", (12, 13): "flush", (0, 13): "ITEM"}
+NAMES = {(1, 4): "prefetched loads arrive, maxima, placement sums",
+         (4, 5): "barrier #2", (5, 2): "scale, origins, carry, DMA issue", (2, 6): "transition: move / rescale accumulators (LDS)",
+         (6, 7): "classify", (7, 8): "own DMA landed", (8, 9): "barrier #3", (9, 15): "transition: float atomics of what left",
+         (15, 10): "pass (gather, gradients, scatter)", (10, 11): "far samples, stores of grad_loc / grad_attn", (11, 14): "next item: decode + issue loads", (14, 12): "barrier #4", (0, 13): "ITEM"}
 fl = sys.argv[1] if len(sys.argv) > 1 else "model"
 lib = _lib.load()
 kw = dict(flavour="model", offset_sigma=6.0) if fl == "wide" else dict(flavour=fl)

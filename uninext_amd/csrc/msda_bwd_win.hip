@@ -23,19 +23,8 @@
 //                four coalesced corner loads, the sample's three gradients by a wave reduction, one full-line float atomic per
 //                corner.  A tile with non-finite inputs takes this path for every sample (NaN / Inf propagate as with float
 //                atomics).
-//   item order   a workgroup walks a contiguous run of its head's tiles DOWN a tile column (round 5).  Consecutive windows then
-//                overlap in their rows: 14 window rows for 8 tile rows on level 0 (10 / 4, 8 / 2, 7 / 1 on the others).
-//   flush        DEFERRED and CARRIED (round 5).  The accumulators of item A are not flushed when A is done but in the head of the
-//                next item B, behind B's window DMA (the flush travels while the value windows land): an accumulator pixel
-//                that is also inside B's window of its level (same window column origin, rows shifted by dy) is MOVED up dy
-//                rows in LDS and keeps collecting; only the rows that leave go to grad_value, as ONE full-line float atomic per
-//                touched pixel.  Round 4 flushed every window whole: 592 slots per item for 170 pixels' worth of queries, 250 MB
-//                written per launch for 114 MB of algorithmic output; a carried transition flushes 260.  Every item keeps its OWN
-//                fixed-point scale (from its own bound, as before): a carried value is re-expressed in the new item's scale
-//                when it is moved -- shifted left (exact) or right (rounded once) -- and an accumulator that would not leave the
-//                new item its full 2^30 of head room (|v| >= 2^30 after the shift: never seen, the bound is that pessimistic) is
-//                flushed instead of carried.  The LDS half of the transition runs in front of barrier #3, its float atomics
-//                BEHIND it (from registers): their acknowledgements drain under the pass instead of under the wait for the DMA.
+//   flush        when the tile is done every touched accumulator pixel inside the image leaves the CU as ONE full-line
+//                float atomic.
 //
 // Per-sample arithmetic (cuh:113-158, refactored as in msda_bwd_tiled): with F / S the first / second pixel of a corner
 // row in this quad's read order and u the bilinear weight of S:
@@ -63,11 +52,10 @@ static_assert(kAccOff % 256 == 0, "slot parity by address bit 7 in both regions"
 struct Meta {
   int sum[4][4];                                                // per level: sum x0, sum y0, count, - (placement)
   int lvl[4][4];                                                // per level: H, W, first pixel, -
+  int org[4][4];                                                // per level: window origin x, y (flush)
   unsigned gmax_bits, amax_bits, pad0, pad1;                    // per tile: max |grad_out|, max_pair sum |attn| (float bits)
-  // what is still in the accumulator windows: the last item's window origins, scale exponent, chain bound, and whether it used them
-  // (two copies, by item parity: an item reads its predecessor's copy in its head AND behind barrier #3, and writes its own)
-  int org[2][4][2];
-  int stE[2], stLds[2];
+  unsigned slot_tab[kSlots];                                    // (level << 28) | (row << 14) | column of a window slot
+  unsigned off_tab[kSlots];                                     // per item: byte offset of the slot's pixel in grad_value (head 0), ~0: outside
 };
 constexpr int kMetaOff = kAccOff + kSlots * 128;
 constexpr int kLdsBytes = kMetaOff + ((sizeof(Meta) + 15) / 16) * 16;
@@ -80,7 +68,7 @@ __device__ unsigned long long g_bwin_prof[kProfBlocks * kWaves * kProfSlots];
 #define BW_STAMP(i)                                                                                          \
   do {                                                                                                       \
     const unsigned blk_ = blockIdx.y * gridDim.x + blockIdx.x;                                               \
-    if ((threadIdx.x & 63) == 0 && item == first + 1 && blk_ < (unsigned)kProfBlocks)                           \
+    if ((threadIdx.x & 63) == 0 && item == kk + K && blk_ < (unsigned)kProfBlocks)                           \
       g_bwin_prof[(blk_ * kWaves + (threadIdx.x >> 6)) * kProfSlots + (i)] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
 #else
@@ -179,10 +167,7 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
   }
   const int TY = (lvH[0] + kTH - 1) / kTH, TX = (lvW[0] + kTW - 1) / kTW;
   const int ntiles = TY * TX, nitems = d.N * ntiles;
-  // a contiguous run of the head's items per workgroup; items are numbered image by image, tile column by tile column, DOWN the
-  // column (tile row fastest): consecutive items of a run are vertical neighbours except at a column's end
-  const int R = (nitems + K - 1) / K, first = kk * R, end = min(first + R, nitems);
-  if (first >= nitems) return;
+  if (kk >= nitems) return;
 
   // ---- once per workgroup: zero region, level table, slot table ---------------------------------------------------------
   for (int o = tid * 16; o < kZeroBytes; o += kT * 16) *reinterpret_cast<f32x4*>(smem + kZeroOff + o) = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -191,9 +176,17 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
     *reinterpret_cast<int4*>(&mt.lvl[tid][0]) = make_int4(sel4(t0, t1, lvH[0], lvH[1], lvH[2], lvH[3]), sel4(t0, t1, lvW[0], lvW[1], lvW[2], lvW[3]),
                                                           sel4(t0, t1, lvS[0], lvS[1], lvS[2], lvS[3]), 0);
   }
+  if (tid < kSlots) {
+    const int l = (tid >= kBase[1] ? 1 : 0) + (tid >= kBase[2] ? 1 : 0) + (tid >= kBase[3] ? 1 : 0);
+    const int rel = tid - (l == 0 ? kBase[0] : l == 1 ? kBase[1] : l == 2 ? kBase[2] : kBase[3]);
+    const int ww = l == 0 ? kWW[0] : l == 1 ? kWW[1] : l == 2 ? kWW[2] : kWW[3];
+    const int r = rel / ww, c = rel - r * ww;
+    mt.slot_tab[tid] = ((unsigned)l << 28) | ((unsigned)r << 14) | (unsigned)c;
+  }
+  static_assert(kSlots <= kT, "one slot-table entry per thread");
   for (int o = tid * 16; o < kSlots * 128; o += kT * 16) *reinterpret_cast<f32x4*>(smem + kAccOff + o) = f32x4{0.f, 0.f, 0.f, 0.f};
   if (tid >= 640 && tid < 656) (&mt.sum[0][0])[tid - 640] = 0;
-  if (tid == 656) { mt.gmax_bits = 0u; mt.amax_bits = 0u; mt.stLds[0] = 0; mt.stLds[1] = 0; mt.stE[0] = 0; mt.stE[1] = 0; }   // (pad0: written by the fetch of every item's first pass before it is read)
+  if (tid == 656) { mt.gmax_bits = 0u; mt.amax_bits = 0u; }   // (pad0: written by the fetch of every item's first pass before it is read)
 
   const uint32_t pixB = (uint32_t)M * 128u;                // bytes from a pixel of head m to the next one
   const uint32_t hoff = (uint32_t)m * 128u;
@@ -201,13 +194,11 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
   // ---- steps: one (item, pass) each.  The loads of a step are issued at the end of the step before it -- for the first
   // pass of an item that is between barrier #4 and the flush of the item before, so that they travel under the flush -- and
   // the step in front of the first item only fetches.
-  int item = first - 1, pass = 0, npass = 1;
-  bool body = false, tail = false;                         // tail: the step behind the last item (it only flushes)
+  int item = kk - K, pass = 0, npass = 1;
+  bool body = false;
   int ogx[4] = {0, 0, 0, 0}, ogy[4] = {0, 0, 0, 0};         // window origins of the item
-  float scale = 1.f;                                       // fixed-point scale of the item's accumulators: 2^E
-  bool use_lds = false;                                    // the item accumulates in LDS (finite, <= 256 pairs)
-  // (the previous item's origins, scale exponent and chain bound -- what its accumulators, still in LDS, are addressed and
-  // scaled by -- live in Meta: written behind barrier #3 of an item, read in the head of the next)
+  float scale = 1.f, inv_scale = 1.f;                      // fixed-point scale of the item's accumulators
+  bool use_lds = false;
   bool live = false;                                       // the fetched step: this quad's (query, head) pair ...
   uint32_t pair = 0;
   v2f lc[4];                                               // ... locations and weights of point k on the four levels
@@ -246,10 +237,12 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
 
 
     if (body) {
-      // (no barrier here: barrier #4 at the end of the previous step is the one everybody left the previous item through; its
-      // accumulators are still in LDS -- see the transition below)
-      BW_STAMP(0);
-      BW_STAMP(1);
+      if (pass == 0) {
+        // ---- barrier #1: everybody has left the previous item (its flush left the accumulator windows all zero) ----------
+        BW_STAMP(0);
+        lds_barrier();
+        BW_STAMP(1);
+      }
 
       auto coord = [&](int l, bool& in) __attribute__((always_inline)) {
         const v2f fWH = {(float)lvW[l], (float)lvH[l]};
@@ -259,88 +252,7 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
       };
 
       BW_STAMP(3);                                           // query decoded, loads issued
-      int E = 0, carry_mask = 0;                             // (pass 0 only) this item's scale exponent; levels that carry
-      int xa[kWH[0]], xb[kWH[1]], xc[kWH[2]];                // what leaves the accumulators in this step's transition (three columns per half wave)
-      // ---- the transition of the previous item's accumulators (they are still in LDS).  LDS half (`move_column`, in front of
-      // barrier #3, under the window DMA): rows that are also in this item's window move up, re-expressed in this item's scale; the
-      // rows that leave are read into registers and cleared.  Memory half (`flush_column`, behind barrier #3): their float atomics.
-      // What the previous item's accumulators are addressed and scaled by is read from Meta where it is needed (uniform values
-      // that would otherwise sit in ~12 vector registers from the item's head to behind barrier #3).
-      struct Prev { int gx[4], gy[4], E; bool lds; float inv; char* gv; };
-      const int ch = tid & 31, hw2 = tid >> 5;               // channel; half wave 0..21
-      const int pbuf = (item - 1 - first) & 1;               // parity of the previous item (the first item finds stLds == 0)
-      auto load_prev = [&]() __attribute__((always_inline)) {
-        Prev P;
-#pragma unroll
-        for (int l = 0; l < 4; ++l) { P.gx[l] = mt.org[pbuf][l][0]; P.gy[l] = mt.org[pbuf][l][1]; }
-        P.E = mt.stE[pbuf];
-        P.lds = mt.stLds[pbuf] != 0;
-        P.inv = ldexpf(1.f, -P.E);
-        const int bA = to_sgpr((int)(((float)max(item - 1, 0) + 0.5f) * __builtin_amdgcn_rcpf((float)ntiles)));
-        P.gv = reinterpret_cast<char*>(grad_value + (int64_t)bA * d.S * M * 32) + hoff + ch * 4;
-        return P;
-      };
-      auto pixel_A = [&](const Prev& P, auto ltag, int c, int r, bool& inside) __attribute__((always_inline)) {   // byte offset of slot (r, c) of the PREVIOUS item's window
-        constexpr int LV = decltype(ltag)::value;
-        const int xA = P.gx[LV] + c, yA = P.gy[LV] + r;
-        inside = (unsigned)xA < (unsigned)lvW[LV] && (unsigned)yA < (unsigned)lvH[LV];
-        return (uint32_t)(lvS[LV] + yA * lvW[LV] + xA) * pixB;
-      };
-      auto move_column = [&](const Prev& P, auto ltag, int c, auto& xs) __attribute__((always_inline)) {
-        constexpr int LV = decltype(ltag)::value, WH = kWH[LV];
-        constexpr uint32_t kRowB = (uint32_t)kWW[LV] * 128u;
-        const int sh = P.E - E;                                // carried values: >> sh (rounded) or << -sh
-        const bool carry = ((carry_mask >> LV) & 1) != 0;
-        const int dy = carry ? ogy[LV] - P.gy[LV] : WH;       // rows [0, dy) leave, row r becomes row r - dy (wave-uniform)
-        const uint32_t a0 = smem_base + (uint32_t)kAccOff + (uint32_t)(kBase[LV] + c) * 128u + (uint32_t)ch * 4u;
-        // read AND clear the whole column (one LDS operation per row), then put back what stays, dy rows up
-#pragma unroll
-        for (int r = 0; r < WH; ++r)
-          xs[r] = __hip_atomic_exchange(reinterpret_cast<lds_int_ptr>((uintptr_t)(a0 + (uint32_t)r * kRowB)), 0, __ATOMIC_RELAXED,
-                                        __HIP_MEMORY_SCOPE_WORKGROUP);
-        // this item may add up to 2^30 to a slot: a carried value has to stay below 2^30 in the new scale
-        const int lim = sh >= 0 ? 0x40000000 : (sh > -30 ? 0x40000000 >> -sh : 0);
-        const int rnd = sh > 0 ? 1 << (min(sh, 31) - 1) : 0, shr = min(max(sh, 0), 31), shl = min(max(-sh, 0), 31);
-        const uint32_t up = (uint32_t)dy * kRowB;
-#pragma unroll
-        for (int r = 0; r < WH; ++r) {
-          if (r >= dy) {                                         // (uniform)
-            const int v = xs[r];
-            if (v != 0) {
-              if (__builtin_expect((v < 0 ? -v : v) < lim, 1)) {
-                const int nv = sh > 31 ? 0 : ((v + rnd) >> shr) << shl;
-                if (nv != 0) *reinterpret_cast<lds_int_ptr>((uintptr_t)(a0 + (uint32_t)r * kRowB - up)) = nv;
-              } else {                                           // (never observed) does not fit: it leaves with the rows above it
-                bool inside;
-                const uint32_t off = pixel_A(P, ltag, c, r, inside);
-                if (inside) atomic_add(reinterpret_cast<float*>(P.gv + (size_t)off), (float)v * P.inv);
-              }
-            }
-            xs[r] = 0;                                           // row r stayed: nothing of it to flush
-          }
-        }
-      };
-      auto flush_column = [&](const Prev& P, auto ltag, int c, const auto& xs) __attribute__((always_inline)) {
-        constexpr int LV = decltype(ltag)::value, WH = kWH[LV];
-#pragma unroll
-        for (int r = 0; r < WH; ++r) {
-          bool inside;
-          const uint32_t off = pixel_A(P, ltag, c, r, inside);
-          if (xs[r] != 0 && inside) atomic_add(reinterpret_cast<float*>(P.gv + (size_t)off), (float)xs[r] * P.inv);
-        }
-      };
-      using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>;
-      using J2 = std::integral_constant<int, 2>; using J3 = std::integral_constant<int, 3>;
-      // 22 half waves: column hw2 of the level-0 window; column hw2 of the 14 + 8 columns of levels 1 / 2's first eight; the last
-      // two columns of level 2 and the eight of level 3 on the first ten half waves
-      const int jb = hw2, jc = hw2 + kT / 32;
-      static_assert(kT / 32 == kWW[0] && kWW[1] + 8 == kT / 32 && kWW[2] == 10 && kWW[3] == 8, "column tasks of the transition");
-      auto columns = [&](const Prev& P, auto&& fn) __attribute__((always_inline)) {
-        fn(P, J0{}, hw2, xa);
-        if (jb < kWW[1]) fn(P, J1{}, jb, xb); else fn(P, J2{}, jb - kWW[1], xb);
-        if (jc < kWW[1] + kWW[2]) fn(P, J2{}, jc - kWW[1], xc); else if (jc < kWW[1] + kWW[2] + kWW[3]) fn(P, J3{}, jc - kWW[1] - kWW[2], xc);
-      };
-      if (pass == 0 && !tail) {
+      if (pass == 0) {
         // ---- fixed-point scale: every slot receives at most (#pairs of the tile) x max |grad_out| x max_pair sum |attn| ----
         {
           float gm = 0.f;
@@ -384,6 +296,19 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
         BW_STAMP(4);                                         // loads arrived; maxima and placement sums added
         lds_barrier();                                       // #2: sums and scale words complete
         BW_STAMP(5);
+        {
+          const float bound = (float)(kL0Waves * 16 + (int)mt.pad0) * __uint_as_float(mt.gmax_bits) * __uint_as_float(mt.amax_bits);
+          // false for NaN / Inf, and for tiles of more than 256 pairs (pyramids with a finer level after the first): every
+          // sample then takes the float-atomic path (thousands of roundings per pixel at a coarse scale add up past 1e-4)
+          use_lds = bound < 0x1p120f && kL0Waves * 16 + (int)mt.pad0 <= 256;   // (>= 2^120: the clamped exponent below could not scale it into int32)
+          if (use_lds && bound > 0.f) {
+            int e;
+            (void)frexpf(bound, &e);                         // bound < 2^e
+            e = max(-90, min(90, 30 - e));
+            scale = ldexpf(1.f, e);
+            inv_scale = ldexpf(1.f, -e);
+          }
+        }
         int myOx, myOy;
         {
           const int4 sm = *reinterpret_cast<const int4*>(&mt.sum[k][0]);
@@ -394,33 +319,12 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
           myOy = (int)floorf((float)sm.y * inv + 0.5f) - (myWH - 2) / 2;
           myOx = max(-1, min(myOx, myW + 1 - myWW));
           myOy = max(-1, min(myOy, myH + 1 - myWH));
+          if (tid < 4) *reinterpret_cast<int2*>(&mt.org[k][0]) = make_int2(myOx, myOy);   // for the flush
         }
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
           ogx[l] = __builtin_amdgcn_readlane(myOx, l);
           ogy[l] = __builtin_amdgcn_readlane(myOy, l);
-        }
-        // ---- the scale of this item; which levels carry their accumulators over from the previous one -------------------------
-        {
-          const int npairs = kL0Waves * 16 + (int)mt.pad0;
-          const float bound = (float)npairs * __uint_as_float(mt.gmax_bits) * __uint_as_float(mt.amax_bits);
-          // false for NaN / Inf, and for tiles of more than 256 pairs (pyramids with a finer level after the first): every
-          // sample then takes the float-atomic path (thousands of roundings per pixel at a coarse scale add up past 1e-4)
-          use_lds = bound < 0x1p120f && npairs <= 256;   // (>= 2^120: the clamped exponent below could not scale it into int32)
-          int e = 0;
-          if (use_lds && bound > 0.f) {
-            (void)frexpf(bound, &e);                         // bound < 2^e: what this item adds to a slot stays below 2^30
-            e = max(-90, min(90, 30 - e));
-          }
-          E = e;
-          scale = ldexpf(1.f, E);
-          // a level carries when its window kept its columns and moved down by less than its height -- in the SAME image (a level
-          // smaller than its window has the same clamped origin in every tile of every image) -- and both items use the LDS
-          if (mt.stLds[pbuf] != 0 && use_lds && itemc - b * ntiles > 0) {
-#pragma unroll
-            for (int l = 0; l < 4; ++l)
-              carry_mask |= (ogx[l] == mt.org[pbuf][l][0] && (unsigned)(ogy[l] - mt.org[pbuf][l][1]) < (unsigned)kWH[l]) ? (1 << l) : 0;
-          }
         }
         // ---- stage the four value windows: LDS-DMA, one instruction = 8 consecutive slots (1 KB) of ONE level per wave ----
         {
@@ -459,19 +363,18 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
         }
       }
 
-      BW_STAMP(2);                                           // origins, window DMA issued
-      if (pass == 0) {
-        // ---- transition, LDS half (in the tail step -- behind the last item -- everything leaves, both halves at once) -------------
-        {
-          const Prev P = load_prev();
-          if (P.lds) columns(P, move_column);
-          if (tail) {
-            if (P.lds) columns(P, flush_column);
-            break;
-          }
-        }
+      // where the flush will send each accumulator slot: thread p computes slot p (the windows travel meanwhile)
+      if (tid < kSlots) {
+        const unsigned e = mt.slot_tab[tid];
+        const int l = (int)(e >> 28), r = (int)((e >> 14) & 0x3fffu), c = (int)(e & 0x3fffu);
+        const bool e0 = (l & 1) != 0, e1 = (l & 2) != 0;
+        const int y = sel4(e0, e1, ogy[0], ogy[1], ogy[2], ogy[3]) + r, x = sel4(e0, e1, ogx[0], ogx[1], ogx[2], ogx[3]) + c;
+        const int Hl = sel4(e0, e1, lvH[0], lvH[1], lvH[2], lvH[3]), Wl = sel4(e0, e1, lvW[0], lvW[1], lvW[2], lvW[3]);
+        const int Sl = sel4(e0, e1, lvS[0], lvS[1], lvS[2], lvS[3]);
+        const bool inside = ((unsigned)y < (unsigned)Hl) & ((unsigned)x < (unsigned)Wl);
+        mt.off_tab[tid] = inside ? (uint32_t)(Sl + y * Wl + x) * pixB : 0xffffffffu;
       }
-      BW_STAMP(6);                                           // transition: accumulators moved
+      BW_STAMP(6);                                           // origins, window DMA issued
       // ---- sample coordinates; near (all four corners inside the level's window or outside the image) or far? -----------
       v2f xy[4];
       uint32_t inb = 0, nb = 0;
@@ -491,30 +394,11 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
       if (pass == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of the value windows has landed
         BW_STAMP(8);
-#ifdef BWIN_T2_EARLY
-        {
-          const Prev P = load_prev();
-          if (P.lds) columns(P, flush_column);
-        }
-#endif
         lds_barrier();                                         // #3 ... and everybody else's
         BW_STAMP(9);
         // the next item's placement sums and scale words (everybody has read this item's; the next adds come after barrier #1)
         if (tid < 16) (&mt.sum[0][0])[tid] = 0;
         if (tid == 16) { mt.gmax_bits = 0u; mt.amax_bits = 0u; }   // (pad0 is rewritten for every item, before barrier #4 of the one before)
-        // ... and what the NEXT step's transition needs to know about this item's accumulators (everybody has read the previous
-        // item's in front of the transition above)
-        if (tid < 4) { mt.org[pbuf ^ 1][tid][0] = sel4(k0, k1, ogx[0], ogx[1], ogx[2], ogx[3]); mt.org[pbuf ^ 1][tid][1] = sel4(k0, k1, ogy[0], ogy[1], ogy[2], ogy[3]); }
-        if (tid == 17) { mt.stE[pbuf ^ 1] = E; mt.stLds[pbuf ^ 1] = use_lds ? 1 : 0; }
-        // ---- transition, memory half: what left the accumulators goes to grad_value, one full-line float atomic per touched pixel;
-        // nothing waits for these until the far samples behind the pass
-#ifndef BWIN_T2_EARLY
-        {
-          const Prev P = load_prev();
-          if (P.lds) columns(P, flush_column);
-        }
-#endif
-        BW_STAMP(15);                                          // transition: atomics issued
       }
 
       if (!l0) __builtin_amdgcn_s_setprio(2);                  // the three youngest waves of the workgroup would finish the pass last
@@ -722,17 +606,17 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
     const bool last = !body || pass + 1 >= npass;
     BW_STAMP(11);
     // ---- the next step: its query, and its loads issued ---------------------------------------------------------------------
-    const int nitem = last ? item + 1 : item, np = last ? 0 : pass + 1;
-    const bool more = nitem < end;
+    const int nitem = last ? item + K : item, np = last ? 0 : pass + 1;
+    const bool more = nitem < nitems;
     // the three youngest waves derive their queries in float + five ds_bpermute and are the last to have their loads out:
     // they go ahead of the other waves' flush (312.8 -> 308.6 us, A/B on one box)
     if (!l0) __builtin_amdgcn_s_setprio(2);
     if (more) {
       const int b2 = to_sgpr((int)(((float)nitem + 0.5f) * __builtin_amdgcn_rcpf((float)ntiles)));
       const int64_t pair_img2 = (int64_t)b2 * d.Lq * M + m;
-      const int tile2 = nitem - b2 * ntiles;                  // tile column by tile column, down the column
-      const int tx2 = to_sgpr((int)(((float)tile2 + 0.5f) * __builtin_amdgcn_rcpf((float)TY)));
-      const int ty2 = tile2 - tx2 * TY;
+      const int tile2 = nitem - b2 * ntiles;
+      const int ty2 = to_sgpr((int)(((float)tile2 + 0.5f) * __builtin_amdgcn_rcpf((float)TX)));
+      const int tx2 = tile2 - ty2 * TX;
         // ---- this quad's query --------------------------------------------------------------------------------------
         uint32_t qidx;
         if (l0) {
@@ -793,15 +677,24 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
     if (body && last) {
       // #4: every wave's atomics are in.  The next item's queries and loads above do not depend on it: the waves of levels 1..3,
       // which finish the pass first, derive theirs while the level-0 waves are still in the pass instead of behind the barrier.
-      // The accumulators stay where they are: the next step's transition moves or flushes them behind its window DMA.
       lds_barrier();
       BW_STAMP(12);
+      // ---- flush: every touched accumulator pixel inside the image leaves as one full-line float atomic (32 lanes x 4 B) ----
+      {
+        const int ch = tid & 31;
+  #pragma unroll 3
+        for (int p = tid >> 5; p < kSlots; p += kT / 32) {
+          // read and clear in one LDS operation: the next item finds the windows zeroed
+          const int raw = __hip_atomic_exchange(reinterpret_cast<lds_int_ptr>((uintptr_t)(smem_base + kAccOff + p * 128 + ch * 4)), 0,
+                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          const uint32_t off = mt.off_tab[p];
+          if (off != 0xffffffffu && raw != 0)
+            atomic_add(reinterpret_cast<float*>(gv_head + (size_t)off) + ch, (float)raw * inv_scale);
+        }
+      }
       BW_STAMP(13);
     }
-    if (!more) {
-      if (tail || !body) break;
-      tail = true;                                           // one more step: the transition alone, everything leaves
-    }
+    if (!more) break;
     item = nitem; pass = np; body = true;
   }
 }
