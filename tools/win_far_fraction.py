@@ -11,8 +11,8 @@ from uninext_amd import workloads
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--flavour", default="model")
-ap.add_argument("--wh", default="14,10,8,7")
-ap.add_argument("--ww", default="22,14,10,8")
+ap.add_argument("--wh", default="12,10,10,10")   # rounds 2-4: 14,10,8,7
+ap.add_argument("--ww", default="20,14,12,10")   # rounds 2-4: 22,14,10,8
 ap.add_argument("--th", type=int, default=8)
 ap.add_argument("--tw", type=int, default=16)
 args = ap.parse_args()

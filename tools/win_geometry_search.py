@@ -1,0 +1,81 @@
+#!/usr/bin/env python
+"""CPU search over the window geometry of msda_fwd_win / msda_bwd_win: per level, the far fraction (in-range samples with a corner
+outside the tile's window, placement rule of the kernels -- tools/win_far_fraction.py) for every candidate (rows, columns), then the
+best combination under the LDS budget (slots of 128 B, every level padded to a multiple of 8 slots: one DMA chunk = 8 slots of one
+level).  Round 5: 14x22 / 10x14 / 8x10 / 7x8 (592 slots) -> 14x20 / 10x14 / 8x12 / 8x10 (600 slots): far 2.22 % -> 1.50 % of the in-range
+samples on the `model` flavour, msda_fwd_win 72 -> 69 us, msda_bwd_win 273 -> 263 us (profiles/r05_window_geometry.txt)."""
+import argparse
+import itertools
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from uninext_amd import workloads  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--flavour", default="model")
+ap.add_argument("--budget", type=int, default=608)
+ap.add_argument("--sigma", type=float, default=1.0)
+args = ap.parse_args()
+TH, TW = 8, 16
+kw = dict(flavour="model", offset_sigma=6.0) if args.flavour == "wide" else dict(flavour=args.flavour, offset_sigma=args.sigma)
+x = workloads.make_inputs("encoder", batch=1, seed=100, device="cpu", **kw)
+levels = [tuple(r) for r in x["shapes"].tolist()]
+loc = x["loc"][0].numpy()    # [Lq, M, L, P, 2]
+H0, W0 = levels[0]
+starts = np.cumsum([0] + [h * w for h, w in levels])
+tile = np.zeros(loc.shape[0], dtype=np.int64)
+TX = (W0 + TW - 1) // TW
+for l, (h, w) in enumerate(levels):
+    q = np.arange(h * w); y, xx = q // w, q % w
+    tx = np.minimum(((2 * xx + 1) * W0) // (2 * TW * w), TX - 1)
+    ty = np.minimum(((2 * y + 1) * H0) // (2 * TH * h), (H0 + TH - 1) // TH - 1)
+    tile[starts[l]:starts[l + 1]] = ty * TX + tx
+ntiles = int(tile.max()) + 1
+first128 = np.zeros(loc.shape[0], dtype=bool)
+for t in range(ntiles):
+    first128[np.nonzero(tile == t)[0][:128]] = True
+M = loc.shape[1]
+cands = {0: [(wh, ww) for wh in (12, 13, 14, 15, 16) for ww in (18, 20, 22, 24)],
+         1: [(wh, ww) for wh in (8, 9, 10, 11, 12) for ww in (12, 14, 16)],
+         2: [(wh, ww) for wh in (7, 8, 9, 10) for ww in (8, 10, 12, 14)],
+         3: [(wh, ww) for wh in (6, 7, 8, 9, 10) for ww in (8, 10, 12)]}
+far = {}
+inr_tot = np.zeros(4)
+for l, (h, w) in enumerate(levels):
+    px = loc[:, :, l, :, 0] * w - 0.5; py = loc[:, :, l, :, 1] * h - 0.5     # [Lq, M, P]
+    inr = (py > -1) & (px > -1) & (py < h) & (px < w)
+    x0 = np.floor(px); y0 = np.floor(py)
+    wsel = inr * first128[:, None, None]
+    sx = np.zeros((ntiles, M)); sy = np.zeros((ntiles, M)); sn = np.zeros((ntiles, M))
+    for m in range(M):
+        sx[:, m] = np.bincount(tile, weights=(x0[:, m] * wsel[:, m]).sum(1), minlength=ntiles)
+        sy[:, m] = np.bincount(tile, weights=(y0[:, m] * wsel[:, m]).sum(1), minlength=ntiles)
+        sn[:, m] = np.bincount(tile, weights=wsel[:, m].sum(1), minlength=ntiles)
+    sn1 = np.maximum(sn, 1)
+    mx, my = np.floor(sx / sn1 + 0.5), np.floor(sy / sn1 + 0.5)
+    inr_tot[l] = inr.sum()
+    for wh, ww in cands[l]:
+        ox = np.maximum(-1, np.minimum(mx - (ww - 2) // 2, w + 1 - ww)); oy = np.maximum(-1, np.minimum(my - (wh - 2) // 2, h + 1 - wh))
+        cx = x0 - ox[tile][:, :, None]; ry = y0 - oy[tile][:, :, None]
+        near = inr & (cx >= 0) & (cx <= ww - 2) & (ry >= 0) & (ry <= wh - 2)
+        far[(l, wh, ww)] = float((inr & ~near).sum())
+pad8 = lambda n: (n + 7) // 8 * 8
+best = []
+for c in itertools.product(*[cands[l] for l in range(4)]):
+    slots = sum(pad8(wh * ww) for wh, ww in c)
+    if slots > args.budget:
+        continue
+    f = sum(far[(l, wh, ww)] for l, (wh, ww) in enumerate(c))
+    best.append((f / inr_tot.sum(), slots, c))
+best.sort()
+print("flavour %s, budget %d slots; far = fraction of the in-range samples" % (args.flavour, args.budget))
+for f, slots, c in best[:12]:
+    print("  far %.3f %%  %3d slots  %s   per level %s" % (100 * f, slots, " / ".join("%dx%d" % g for g in c),
+          " ".join("%.2f" % (100 * far[(l, wh, ww)] / inr_tot[l]) for l, (wh, ww) in enumerate(c))))
+for name, c in (("round 4", ((14, 22), (10, 14), (8, 10), (7, 8))), ("round 5 first try", ((14, 20), (10, 14), (8, 12), (8, 10))), ("round 5", ((12, 20), (10, 14), (10, 12), (10, 10)))):
+    if all((l, wh, ww) in far for l, (wh, ww) in enumerate(c)):
+        print("  %s: far %.3f %%  %d slots" % (name, 100 * sum(far[(l, wh, ww)] for l, (wh, ww) in enumerate(c)) / inr_tot.sum(),
+                                              sum(pad8(wh * ww) for wh, ww in c)))

@@ -9,8 +9,9 @@
 //
 //   work item    (image, head, 8 x 16 tile of level-0 pixels) + the tile's queries of levels 1..3 (the same exact
 //                partition), 704-thread workgroups: waves 0..7 = the tile's rows, waves 8..10 = levels 1..3, one pass.
-//   LDS          per level a window of `value` pixels (LDS-DMA, as in the forward kernel: 74 KB) AND a window of the same
-//                geometry of 32-bit FIXED-POINT accumulators for grad_value (74 KB; ds_add_f32 costs ~190 clocks per wave
+//   LDS          per level a window of `value` pixels (LDS-DMA, as in the forward kernel: 12x20 / 10x14 / 10x12 / 10x10 pixels, 76 KB;
+//                round 5 -- rounds 3-4 had 14x22 / 10x14 / 8x10 / 7x8: 273 -> 263 us, see msda_fwd_win.hip) AND a window of the same
+//                geometry of 32-bit FIXED-POINT accumulators for grad_value (76 KB; ds_add_f32 costs ~190 clocks per wave
 //                instruction on gfx950, ds_add_u32 4.4 -- tools/micro/lds_atomic_bench.cpp; the per-tile power-of-two scale
 //                comes from a bound that cannot overflow, msda_bwd_tiled.hip / include/msda_hip.h).  One workgroup per CU.
 //   gather       a quad of lanes per (query, head) pair; lane k owns the 16-byte pieces k and k + 4 of a pixel; corner
@@ -41,9 +42,9 @@ namespace {
 constexpr int kL0Waves = 8, kRestWaves = 3, kWaves = kL0Waves + kRestWaves, kT = kWaves * 64;
 constexpr int kRestQuads = kRestWaves * 16;
 constexpr int kTH = 8, kTW = 16;
-constexpr int kWH[4] = {14, 10, 8, 7};
-constexpr int kWW[4] = {22, 14, 10, 8};                         // even: slot parity == column parity in every row
-constexpr int kBase[5] = {0, 312, 456, 536, 592};               // first slot of each window (multiples of 8: DMA chunks)
+constexpr int kWH[4] = {12, 10, 10, 10};
+constexpr int kWW[4] = {20, 14, 12, 10};                        // even: slot parity == column parity in every row
+constexpr int kBase[5] = {0, 240, 384, 504, 608};               // first slot of each window (multiples of 8: DMA chunks)
 constexpr int kSlots = kBase[4];
 constexpr int kZeroOff = kSlots * 128;                          // all-zero region: read target of dead / far samples
 constexpr int kZeroBytes = kWW[0] * 128 + 256;

@@ -10,8 +10,11 @@
 //   work item  = (image b, head m, 8 x 16 tile of level-0 pixels).  Its queries are the pixels of EVERY level whose
 //                centre falls into the tile's normalised rectangle (an exact partition of the S queries in integer
 //                arithmetic): 128 + 32 + 8 + 2 = 170 queries at the R50 shapes.
-//   windows    = per level a WH x WW block of head m's value rows (128 B per pixel), 14x22 / 10x14 / 8x10 / 7x8
-//                pixels = 584 slots (592 with chunk padding) = 74 KB, so that TWO 512-thread workgroups fit a CU.  A window is placed where
+//   windows    = per level a WH x WW block of head m's value rows (128 B per pixel), 12x20 / 10x14 / 10x12 / 10x10
+//                pixels = 600 slots (608 with chunk padding) = 76 KB, so that TWO 512-thread workgroups fit a CU (round 5: rounds 2-4 had
+//                14x22 / 10x14 / 8x10 / 7x8 -- half of the far samples sat on levels 2 / 3; tools/win_geometry_search.py picks the
+//                geometry that minimises them under the LDS budget over sampling spreads of 1-3 px: 2.2 -> 1.4 % at 1 px, 12.7 -> 8.2 %
+//                at 2 px; 72 -> 69 us on the bench's inputs, profiles/r05_window_geometry.txt).  A window is placed where
 //                the tile's own samples fall: the mean top-left corner of the in-range samples of the first 128
 //                queries, reduced over the workgroup with integer LDS atomics.  Pixels outside the image are staged
 //                as zeros (out-of-range raw buffer offsets), so the zero padding of border samples needs no masks.
@@ -61,9 +64,9 @@ constexpr int kT = 512, kWaves = kT / 64, kQuads = kT / 4;
 constexpr double kFarFractionMax = 0.33;
 constexpr unsigned kReprobe = 64, kReportEvery = 8;
 constexpr int kTH = 8, kTW = 16;
-constexpr int kWH[4] = {14, 10, 8, 7};
-constexpr int kWW[4] = {22, 14, 10, 8};                         // even: slot parity == column parity in every row
-constexpr int kBase[5] = {0, 312, 456, 536, 592};               // first slot of each window, multiples of 8: a 1 KB
+constexpr int kWH[4] = {12, 10, 10, 10};
+constexpr int kWW[4] = {20, 14, 12, 10};                        // even: slot parity == column parity in every row
+constexpr int kBase[5] = {0, 240, 384, 504, 608};               // first slot of each window, multiples of 8: a 1 KB
                                                                 // DMA chunk (8 slots) never straddles two levels
 static_assert(kBase[1] >= kWH[0] * kWW[0] && kBase[2] >= kBase[1] + kWH[1] * kWW[1] &&
               kBase[3] >= kBase[2] + kWH[2] * kWW[2] && kBase[4] >= kBase[3] + kWH[3] * kWW[3], "window table");
