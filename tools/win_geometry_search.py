@@ -18,6 +18,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--flavour", default="model")
 ap.add_argument("--budget", type=int, default=608)
 ap.add_argument("--sigma", type=float, default=1.0)
+ap.add_argument("--big", action="store_true", help="candidate windows up to msda_bwd_tiled's sizes (accumulator windows only: 832 slots)")
 args = ap.parse_args()
 TH, TW = 8, 16
 kw = dict(flavour="model", offset_sigma=6.0) if args.flavour == "wide" else dict(flavour=args.flavour, offset_sigma=args.sigma)
@@ -38,10 +39,16 @@ first128 = np.zeros(loc.shape[0], dtype=bool)
 for t in range(ntiles):
     first128[np.nonzero(tile == t)[0][:128]] = True
 M = loc.shape[1]
-cands = {0: [(wh, ww) for wh in (12, 13, 14, 15, 16) for ww in (18, 20, 22, 24)],
-         1: [(wh, ww) for wh in (8, 9, 10, 11, 12) for ww in (12, 14, 16)],
-         2: [(wh, ww) for wh in (7, 8, 9, 10) for ww in (8, 10, 12, 14)],
-         3: [(wh, ww) for wh in (6, 7, 8, 9, 10) for ww in (8, 10, 12)]}
+if args.big:
+    cands = {0: [(wh, ww) for wh in (12, 13, 14, 15, 16) for ww in (20, 22, 24, 26)],
+             1: [(wh, ww) for wh in (10, 11, 12, 13, 14) for ww in (14, 16, 18, 20)],
+             2: [(wh, ww) for wh in (9, 10, 11, 12, 13, 14) for ww in (10, 12, 14, 16)],
+             3: [(wh, ww) for wh in (8, 9, 10, 11, 12, 13) for ww in (9, 10, 12, 14, 16)]}
+else:
+  cands = {0: [(wh, ww) for wh in (12, 13, 14, 15, 16) for ww in (18, 20, 22, 24)],
+           1: [(wh, ww) for wh in (8, 9, 10, 11, 12) for ww in (12, 14, 16)],
+           2: [(wh, ww) for wh in (7, 8, 9, 10) for ww in (8, 10, 12, 14)],
+           3: [(wh, ww) for wh in (6, 7, 8, 9, 10) for ww in (8, 10, 12)]}
 far = {}
 inr_tot = np.zeros(4)
 for l, (h, w) in enumerate(levels):
@@ -62,7 +69,7 @@ for l, (h, w) in enumerate(levels):
         cx = x0 - ox[tile][:, :, None]; ry = y0 - oy[tile][:, :, None]
         near = inr & (cx >= 0) & (cx <= ww - 2) & (ry >= 0) & (ry <= wh - 2)
         far[(l, wh, ww)] = float((inr & ~near).sum())
-pad8 = lambda n: (n + 7) // 8 * 8
+pad8 = (lambda n: n) if args.big else (lambda n: (n + 7) // 8 * 8)
 best = []
 for c in itertools.product(*[cands[l] for l in range(4)]):
     slots = sum(pad8(wh * ww) for wh, ww in c)
@@ -75,6 +82,12 @@ print("flavour %s, budget %d slots; far = fraction of the in-range samples" % (a
 for f, slots, c in best[:12]:
     print("  far %.3f %%  %3d slots  %s   per level %s" % (100 * f, slots, " / ".join("%dx%d" % g for g in c),
           " ".join("%.2f" % (100 * far[(l, wh, ww)] / inr_tot[l]) for l, (wh, ww) in enumerate(c))))
+if args.big:
+    for m in (8,):
+        c = tuple((ey + m, ex + m) for ex, ey in ((16, 8), (8, 4), (4, 2), (2, 1)))
+        if all((l, wh, ww) in far for l, (wh, ww) in enumerate(c)):
+            print("  msda_bwd_tiled today (uniform margin %d): far %.3f %%  %d slots  %s" % (m, 100 * sum(far[(l, wh, ww)] for l, (wh, ww) in enumerate(c)) / inr_tot.sum(),
+                  sum(wh * ww for wh, ww in c), " / ".join("%dx%d" % g for g in c)))
 for name, c in (("round 4", ((14, 22), (10, 14), (8, 10), (7, 8))), ("round 5 first try", ((14, 20), (10, 14), (8, 12), (8, 10))), ("round 5", ((12, 20), (10, 14), (10, 12), (10, 10)))):
     if all((l, wh, ww) in far for l, (wh, ww) in enumerate(c)):
         print("  %s: far %.3f %%  %d slots" % (name, 100 * sum(far[(l, wh, ww)] for l, (wh, ww) in enumerate(c)) / inr_tot.sum(),

@@ -127,12 +127,18 @@ __device__ __forceinline__ void bwd_tiled_body(const float* __restrict__ grad_ou
     mt.TY = (H0 + kBTH - 1) / kBTH;
     mt.TX = (W0 + kBTW - 1) / kBTW;
     int total = 0;
+    // Window of a level = the tile's footprint on it + a margin.  Round 5: the margin GROWS with the level (-2 / 0 / +2 / +2 around the
+    // common value, which is the largest that fits): the samples spread by the same number of pixels on every level, but on a fine level
+    // only the queries near the tile's edge can leave the window, on a coarse one (footprint 2 x 1) every query can.  At the R50 shapes:
+    // 14x22 / 12x16 / 12x14 / 11x12 instead of 16x24 / 12x16 / 10x12 / 9x10 -- far samples 4.6 -> 3.0 % at a spread of 2 px, 14.7 -> ~11 % at
+    // 3 px (tools/win_geometry_search.py --big; each far sample costs four full-line float atomics here).
     for (int margin = 10; margin >= 0; --margin) {
       total = 0;
       for (int l = 0; l < L; ++l) {
         const int ex = (kBTW * mt.W[l] + W0 - 1) / W0, ey = (kBTH * mt.H[l] + H0 - 1) / H0;
-        mt.WW[l] = min(mt.W[l], ex + margin);
-        mt.WH[l] = min(mt.H[l], ey + margin);
+        const int ml = max(0, margin + (l == 0 ? -2 : l == 1 ? 0 : 2));
+        mt.WW[l] = min(mt.W[l], ex + ml);
+        mt.WH[l] = min(mt.H[l], ey + ml);
         total += mt.WW[l] * mt.WH[l];
       }
       if (total <= kBSlots) break;
