@@ -146,3 +146,33 @@ def test_environment_switches_are_the_documented_ones():
     assert seen == allowed, (sorted(seen - allowed), sorted(allowed - seen))
     for v in allowed:
         assert v in doc, v
+
+
+def test_experiment_patches_apply_as_documented():
+    """uninext_amd/csrc/experiments/README.md says which of the archived experiment patches apply to the current sources, and how:
+    held here, so that the archive does not rot silently (dry runs only; nothing is modified)."""
+    import re
+    import shutil
+    import subprocess
+    if shutil.which("patch") is None or shutil.which("git") is None:
+        pytest.skip("needs patch and git")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exp = os.path.join(root, "uninext_amd", "csrc", "experiments")
+    rows = [l for l in open(os.path.join(exp, "README.md")) if l.startswith("| `") and ".patch" in l]
+    checked = 0
+    for row in rows:
+        cells = [c.strip() for c in row.strip().strip("|").split("|")]
+        patch = re.search(r"`([\w.]+\.patch)`", cells[0]).group(1)
+        how = cells[-1]
+        path = os.path.join(exp, patch)
+        assert os.path.exists(path), patch
+        if not how.startswith("current tree"):
+            continue
+        if "git apply" in how:
+            cmd, cwd = ["git", "apply", "--check", path], root
+        else:
+            cmd, cwd = ["patch", "-p0", "--dry-run", "-F3", "-i", path], os.path.join(root, "uninext_amd", "csrc")
+        res = subprocess.run(cmd, cwd=cwd, capture_output=True, text=True)
+        assert res.returncode == 0, (patch, res.stdout[-400:], res.stderr[-400:])
+        checked += 1
+    assert checked >= 6
