@@ -31,6 +31,9 @@
 // row in this quad's read order and u the bilinear weight of S:
 //   top = F_top + u (S_top - F_top), bot = F_bot + u (S_bot - F_bot), val = top + lh (bot - top)
 //   grad_attn = sum_c g_c val_c;  d val / d y = bot - top;  d val / d x = +-[hh (S_top - F_top) + lh (S_bot - F_bot)]
+// Round 5: u, lh do not depend on the channel, so a sample needs only the four sums  sum_c g_c F_c  and  sum_c g_c S_c  of its two
+// corner rows (4 packed FMAs per channel pair; everything else on the reduced sums), and the scatter multiplies two channels per
+// v_pk_mul_f32: 3965 -> 3389 vector instructions in the kernel, 264.5 -> 260.7 us (profiles/r05_backward_packed.txt).
 #include <cstdlib>
 #include <type_traits>
 
@@ -453,24 +456,25 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
         constexpr int LV = decltype(ltag)::value, PT = decltype(ptag)::value;
         const float u = qbf<PT>(s.u), lh = qbf<PT>(s.lh);
         const float hh = 1.f - lh;
-        const v2f U = {u, u};
         // the three sums are linear in the two corner rows (round 4): with A_r = sum_c g_c (F_c + u (S_c - F_c)) and
         // D_r = sum_c g_c (S_c - F_c) per row r:  grad_attn = hh A_top + lh A_bot,  d val / d x = hh D_top + lh D_bot,
-        // d val / d y = A_bot - A_top -- 8 packed operations per channel pair instead of 11
-        v2f At = {0.f, 0.f}, Dt = {0.f, 0.f}, Ab = {0.f, 0.f}, Db = {0.f, 0.f};
+        // d val / d y = A_bot - A_top.  Round 5: u does not depend on the channel either, so a row needs only sum_c g_c F_c and
+        // sum_c g_c S_c -- 4 packed FMAs per channel pair (was 8 + two subtractions that compiled to four v_sub_f32), then
+        // D_r = sum gS - sum gF and A_r = sum gF + u D_r on the reduced sums
+        v2f SFt = {0.f, 0.f}, SSt = {0.f, 0.f}, SFb = {0.f, 0.f}, SSb = {0.f, 0.f};
         auto chan_pair = [&](v2f Ft, v2f St, v2f Fb, v2f Sb, v2f G) __attribute__((always_inline)) {
-          const v2f tt = St - Ft, tb = Sb - Fb;
-          const v2f vt = __builtin_elementwise_fma(U, tt, Ft), vb = __builtin_elementwise_fma(U, tb, Fb);
-          At = __builtin_elementwise_fma(G, vt, At);
-          Dt = __builtin_elementwise_fma(G, tt, Dt);
-          Ab = __builtin_elementwise_fma(G, vb, Ab);
-          Db = __builtin_elementwise_fma(G, tb, Db);
+          SFt = __builtin_elementwise_fma(G, Ft, SFt);
+          SSt = __builtin_elementwise_fma(G, St, SSt);
+          SFb = __builtin_elementwise_fma(G, Fb, SFb);
+          SSb = __builtin_elementwise_fma(G, Sb, SSb);
         };
         chan_pair(v2f{top.Fa[0], top.Fa[1]}, v2f{top.Sa[0], top.Sa[1]}, v2f{bot.Fa[0], bot.Fa[1]}, v2f{bot.Sa[0], bot.Sa[1]}, v2f{gA[0], gA[1]});
         chan_pair(v2f{top.Fa[2], top.Fa[3]}, v2f{top.Sa[2], top.Sa[3]}, v2f{bot.Fa[2], bot.Fa[3]}, v2f{bot.Sa[2], bot.Sa[3]}, v2f{gA[2], gA[3]});
         chan_pair(v2f{top.Fb[0], top.Fb[1]}, v2f{top.Sb[0], top.Sb[1]}, v2f{bot.Fb[0], bot.Fb[1]}, v2f{bot.Sb[0], bot.Sb[1]}, v2f{gB[0], gB[1]});
         chan_pair(v2f{top.Fb[2], top.Fb[3]}, v2f{top.Sb[2], top.Sb[3]}, v2f{bot.Fb[2], bot.Fb[3]}, v2f{bot.Sb[2], bot.Sb[3]}, v2f{gB[2], gB[3]});
-        const float at = At.x + At.y, ab = Ab.x + Ab.y, dt = Dt.x + Dt.y, db = Db.x + Db.y;
+        const float sft = SFt.x + SFt.y, sst = SSt.x + SSt.y, sfb = SFb.x + SFb.y, ssb = SSb.x + SSb.y;
+        const float dt = sst - sft, db = ssb - sfb;
+        const float at = fmaf(u, dt, sft), ab = fmaf(u, db, sfb);
         const float ra = quad_sum(fmaf(lh, ab, hh * at)), rw = quad_sum(fmaf(lh, db, hh * dt)), rh = quad_sum(ab - at);
         const bool near_mine = ((nb >> LV) & 1u) != 0u;
         const bool mine = (k == PT) & near_mine;               // this lane's own sample (far ones were done above, dead ones stay 0)
@@ -487,14 +491,20 @@ msda_bwd_win(const float* __restrict__ grad_out, const float* __restrict__ value
           constexpr uint32_t kRowB = (uint32_t)kWW[LV] * 128u;
           const uint32_t aLr = (qb<PT>(s.aL) + 4u * (uint32_t)k) ^ rot;
           const float wTL = qbf<PT>(s.wT.x), wTR = qbf<PT>(s.wT.y), wBL = qbf<PT>(s.wB.x), wBR = qbf<PT>(s.wB.y);
+          const v2f WTL = {wTL, wTL}, WTR = {wTR, wTR}, WBL = {wBL, wBL}, WBR = {wBR, wBR};
 #pragma unroll
-          for (int t = 0; t < 8; ++t) {
-            const uint32_t a = aLr ^ (16u * (uint32_t)t);
-            const float g = gi[t];
-            lds_add(a, cvt_rn_i32(wTL * g));
-            lds_add(a + 128u, cvt_rn_i32(wTR * g));
-            lds_add(a + kRowB, cvt_rn_i32(wBL * g));
-            lds_add(a + kRowB + 128u, cvt_rn_i32(wBR * g));
+          for (int t = 0; t < 8; t += 2) {                     // two channels per v_pk_mul_f32
+            const uint32_t a = aLr ^ (16u * (uint32_t)t), b = aLr ^ (16u * (uint32_t)(t + 1));
+            const v2f g = {gi[t], gi[t + 1]};
+            const v2f pTL = WTL * g, pTR = WTR * g, pBL = WBL * g, pBR = WBR * g;
+            lds_add(a, cvt_rn_i32(pTL.x));
+            lds_add(a + 128u, cvt_rn_i32(pTR.x));
+            lds_add(a + kRowB, cvt_rn_i32(pBL.x));
+            lds_add(a + kRowB + 128u, cvt_rn_i32(pBR.x));
+            lds_add(b, cvt_rn_i32(pTL.y));
+            lds_add(b + 128u, cvt_rn_i32(pTR.y));
+            lds_add(b + kRowB, cvt_rn_i32(pBL.y));
+            lds_add(b + kRowB + 128u, cvt_rn_i32(pBR.y));
           }
         }
         __builtin_amdgcn_sched_barrier(0);
