@@ -176,3 +176,27 @@ def test_experiment_patches_apply_as_documented():
         assert res.returncode == 0, (patch, res.stdout[-400:], res.stderr[-400:])
         checked += 1
     assert checked >= 6
+
+
+def test_window_geometry_is_the_same_everywhere():
+    """The forward and the backward window kernel must place the same windows (the backward runs where the forward's reports said
+    the samples stay inside THEIR windows), and the CPU model of the far fraction (tools/win_far_fraction.py, the tool the
+    geometry was chosen with) must model those windows by default."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def geometry(path):
+        src = open(os.path.join(root, path)).read()
+        wh = re.search(r"constexpr int kWH\[4\] = \{([\d, ]+)\}", src).group(1)
+        ww = re.search(r"constexpr int kWW\[4\] = \{([\d, ]+)\}", src).group(1)
+        return [int(v) for v in wh.split(",")], [int(v) for v in ww.split(",")]
+
+    fwd = geometry("uninext_amd/csrc/msda_fwd_win.hip")
+    bwd = geometry("uninext_amd/csrc/msda_bwd_win.hip")
+    assert fwd == bwd
+    wh, ww = fwd
+    assert all(w % 2 == 0 for w in ww)                                  # slot parity == column parity in every row
+    slots = sum(h * w for h, w in zip(wh, ww))
+    assert slots % 8 == 0 and slots * 128 <= 80 * 1024                  # two forward workgroups (windows + zero region) per CU
+    tool = open(os.path.join(root, "tools", "win_far_fraction.py")).read()
+    assert '"--wh", default="%s"' % ",".join(map(str, wh)) in tool
+    assert '"--ww", default="%s"' % ",".join(map(str, ww)) in tool
