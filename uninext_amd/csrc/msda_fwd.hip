@@ -617,6 +617,11 @@ int launch_forward<float>(int variant, const float* value, const int64_t* shapes
     return launch_forward_win2(value, shapes, lsi, loc, attn, d, out, stream);
   }
 #endif
+  if (variant == kWinL && !winl_forward_ok(d)) variant = lg3_ok(d) ? kLaneGroupL3 : kLaneGroup;
+  if (variant == kWinL) {
+    *kernel_name = "msda_fwd_winl";
+    return launch_forward_winl(value, shapes, lsi, loc, attn, d, out, stream);
+  }
   if (variant == kWin && !win_forward_ok(d)) variant = lg3_ok(d) ? kLaneGroupL3 : kLaneGroup;
   if (variant == kWin) {
     *kernel_name = "msda_fwd_win";
