@@ -82,7 +82,7 @@ def test_full_size_forward_every_query(flavour, dev, api):
     MSDA, lib = api
     x = _inputs(flavour, workloads.R50_LEVELS_INFER, 13, dev)
     ref = msda_oracle.forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
-    for variant in carried("forward", "auto", "msda_fwd_lanegroup", "msda_fwd_win", "msda_fwd_win2", "msda_fwd_win3", "msda_fwd_win4"):
+    for variant in carried("forward", "auto", "msda_fwd_lanegroup", "msda_fwd_win", "msda_fwd_win2", "msda_fwd_win3", "msda_fwd_win4", "msda_fwd_winl", "msda_fwd_winp"):
         out = _fwd(MSDA, lib, x, variant)
         want = lib.last_kernel("forward")
         assert want in (("msda_fwd_lg3", "msda_fwd_win") if variant == "auto" else (variant,))
@@ -91,7 +91,7 @@ def test_full_size_forward_every_query(flavour, dev, api):
         assert err < 1e-4, (variant, err)
 
 
-@pytest.mark.parametrize("kernel", carried("forward", "msda_fwd_win", "msda_fwd_win2", "msda_fwd_win3", "msda_fwd_win4"))
+@pytest.mark.parametrize("kernel", carried("forward", "msda_fwd_win", "msda_fwd_win2", "msda_fwd_win3", "msda_fwd_win4", "msda_fwd_winl", "msda_fwd_winp"))
 @pytest.mark.parametrize("flavour", ["model", "uniform", "wide"])
 @pytest.mark.parametrize("levels", ODD_PYRAMIDS)
 def test_window_forward_on_odd_pyramids(levels, flavour, kernel, dev, api):
@@ -518,7 +518,7 @@ print("KERNELS", captured_kernel, eager_kernel, _lib.forward_locality()[0])
     assert line[1] == "msda_fwd_lg3" and line[2] == "msda_fwd_win" and int(line[3]) == 1, line   # captured: gather; eager: window, 1 report
 
 
-@pytest.mark.parametrize("variant", carried("forward", "auto", "msda_fwd_win", "msda_fwd_win2", "msda_fwd_win3", "msda_fwd_win4", "msda_fwd_lg3", "msda_fwd_lanegroup"))
+@pytest.mark.parametrize("variant", carried("forward", "auto", "msda_fwd_win", "msda_fwd_win2", "msda_fwd_win3", "msda_fwd_win4", "msda_fwd_winl", "msda_fwd_winp", "msda_fwd_lg3", "msda_fwd_lanegroup"))
 def test_encoder_shaped_reference_fixture_forward(variant, dev, api):
     """Every kernel an encoder-shaped call can take, against the REFERENCE's own output for that shape
     (tests/golden/encshape_s1065_m2.npz, minted by ms_deform_attn_core_pytorch in float64): abs 1e-4."""
@@ -614,7 +614,7 @@ def test_encoder_kernels_on_other_batch_sizes_and_head_counts(heads, batch, dev,
     levels = ((25, 42), (13, 21), (7, 11), (4, 6))
     x = workloads.make_inputs("encoder", "model", batch=batch, levels=levels, heads=heads, seed=50 + heads, device=dev)
     ref = msda_oracle.forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
-    for kernel in carried("forward", "msda_fwd_win", "msda_fwd_win2", "msda_fwd_win3", "msda_fwd_win4"):
+    for kernel in carried("forward", "msda_fwd_win", "msda_fwd_win2", "msda_fwd_win3", "msda_fwd_win4", "msda_fwd_winl", "msda_fwd_winp"):
         out = _fwd(MSDA, lib, x, kernel)
         assert lib.last_kernel("forward") == kernel
         assert float(np.abs(out.cpu().numpy().astype(np.float64) - ref).max()) < 1e-4, kernel
@@ -645,7 +645,7 @@ def test_window_forward_far_path_with_odd_head_counts(heads, flavour, dev, api):
     for levels in (ODD_PYRAMIDS[2], ODD_PYRAMIDS[4]):
         x = workloads.make_inputs("encoder", batch=2, levels=levels, heads=heads, seed=60 + heads, device=dev, **kw)
         ref = msda_oracle.forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
-        for kernel in carried("forward", "msda_fwd_win", "msda_fwd_win2", "msda_fwd_win3", "msda_fwd_win4"):
+        for kernel in carried("forward", "msda_fwd_win", "msda_fwd_win2", "msda_fwd_win3", "msda_fwd_win4", "msda_fwd_winl", "msda_fwd_winp"):
             out = _fwd(MSDA, lib, x, kernel)
             assert lib.last_kernel("forward") == kernel
             assert float(np.abs(out.cpu().numpy().astype(np.float64) - ref).max()) < 1e-4, (levels, heads, kernel)

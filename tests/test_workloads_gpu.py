@@ -44,7 +44,7 @@ def test_named_workload_forward_and_backward_every_query(name, flavour, dev, api
     Lq = x["loc"].shape[1]
     encoder = w["kind"] == "encoder"
     ref = msda_oracle.forward(x["value"].double(), x["shapes"], x["lsi"], x["loc"].double(), x["attn"].double())
-    variants = carried("forward", "auto", "msda_fwd_win", "msda_fwd_win2", "msda_fwd_win3", "msda_fwd_win4", "msda_fwd_lg3") if encoder else ("auto",)
+    variants = carried("forward", "auto", "msda_fwd_win", "msda_fwd_win2", "msda_fwd_win3", "msda_fwd_win4", "msda_fwd_winl", "msda_fwd_winp", "msda_fwd_lg3") if encoder else ("auto",)
     for variant in variants:
         lib.set_variant("forward", variant)
         try:

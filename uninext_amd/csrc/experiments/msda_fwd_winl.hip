@@ -35,7 +35,7 @@
 #include <cstring>
 #include <type_traits>
 
-#include "msda_common.hpp"
+#include "../msda_common.hpp"
 
 #ifndef WINL_LB
 #define WINL_LB 3
@@ -604,7 +604,7 @@ int launch_forward_winl(const float* value, const int64_t* shapes, const int64_t
   if (int rc = ensure_dynamic_lds(fn, kLdsBytes, lds_opted_in)) return rc;
   int K = d.N * ((d.S + 127) / 128);
   K = std::min(K, std::max(1, (2 * cus) / std::max(d.M, 1)));
-  if (const char* e = std::getenv("MSDA_WINL_K")) K = std::atoi(e);   // TEMP experiment
+  if (const int k = ab_env_int("MSDA_WINL_K", 0)) K = k;   // A/B: workgroups per head
   if (K < 1) K = 1;
   if (K > 65535) K = 65535;
   hipLaunchKernelGGL(msda_fwd_winl, dim3((unsigned)d.M, (unsigned)K), dim3(kT), kLdsBytes, stream, value, shapes, lsi, loc,

@@ -31,7 +31,7 @@ constexpr int kNumFwdVariants = msda::kNumVariants, kNumBwdVariants = 8;
 const char* const kFwdNames[kNumFwdVariants] = {
     "auto", "msda_fwd_generic", "msda_fwd_lanegroup", MSDA_EXP("msda_fwd_tiled"), MSDA_EXP("msda_fwd_tiled_l0"),
     MSDA_EXP("msda_fwd_tiled_l0big"), MSDA_EXP("msda_fwd_lgcl"), "msda_fwd_lg3", MSDA_EXP("msda_fwd_lgp"), "msda_fwd_win",
-    MSDA_EXP("msda_fwd_win2"), MSDA_EXP("msda_fwd_win3"), MSDA_EXP("msda_fwd_win4"), "msda_fwd_winl"};
+    MSDA_EXP("msda_fwd_win2"), MSDA_EXP("msda_fwd_win3"), MSDA_EXP("msda_fwd_win4"), MSDA_EXP("msda_fwd_winl"), MSDA_EXP("msda_fwd_winp")};
 const char* const kBwdNames[kNumBwdVariants] = {"auto", "msda_bwd_generic", "msda_bwd_lanegroup", "msda_bwd_tiled",
                                                 "msda_bwd_win", "msda_bwd_dec", "msda_bwd_regions", MSDA_EXP("msda_bwd_win2")};
 #undef MSDA_EXP

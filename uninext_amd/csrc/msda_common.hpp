@@ -113,7 +113,7 @@ constexpr int ab_env_int(const char*, int dflt) { return dflt; }
 
 // Variant numbering shared with include/msda_hip.h.
 enum Variant { kAuto = 0, kGeneric = 1, kLaneGroup = 2, kTiled = 3, kTiledL0 = 4, kTiledL0Big = 5, kLaneGroupCL = 6,
-               kLaneGroupL3 = 7, kLaneGroupP = 8, kWin = 9, kWin2 = 10, kWin3 = 11, kWin4 = 12, kWinL = 13, kNumVariants = 14 };
+               kLaneGroupL3 = 7, kLaneGroupP = 8, kWin = 9, kWin2 = 10, kWin3 = 11, kWin4 = 12, kWinL = 13, kWinP = 14, kNumVariants = 15 };
 
 // msda_fwd.hip: forward with the MSDeformAttn prologue (softmax + sampling locations) fused in.
 bool fused_forward_ok(const Dims& d, int ref_dim);
@@ -174,9 +174,14 @@ void reset_call_site(int slot);                  // include/msda_hip.h: msda_hip
 int launch_forward_win(const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc, const float* attn,
                        const Dims& d, float* out, hipStream_t stream);
 
-// msda_fwd_winl.hip: the window kernel with ONE lane per (query, head) pair (same preconditions as msda_fwd_win).
+// experiments/msda_fwd_winl.hip (round 6): the window kernel with scalar level constants, a pair's points split over two lanes (same preconditions as msda_fwd_win).
 bool winl_forward_ok(const Dims& d);
 int launch_forward_winl(const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc, const float* attn,
+                        const Dims& d, float* out, hipStream_t stream);
+
+// experiments/msda_fwd_winp.hip (round 6): the pipelined window kernel (one 12-wave workgroup per CU, two window sets; same preconditions).
+bool winp_forward_ok(const Dims& d);
+int launch_forward_winp(const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc, const float* attn,
                         const Dims& d, float* out, hipStream_t stream);
 
 // msda_fwd_win2.hip: the one-pass, 11-wave generation of the window kernel (same preconditions).

@@ -601,6 +601,16 @@ int launch_forward<float>(int variant, const float* value, const int64_t* shapes
   if (variant == kAuto) variant = win_forward_auto(d, stream) ? kWin : (lg3_ok(d) ? kLaneGroupL3 : (lg ? kLaneGroup : kGeneric));
   else drop_call_context();
 #ifdef MSDA_EXPERIMENTS   // the generations of the window kernel that lost their A/B (experiments/, `make experiments`)
+  if (variant == kWinP && !winp_forward_ok(d)) variant = lg3_ok(d) ? kLaneGroupL3 : kLaneGroup;
+  if (variant == kWinP) {
+    *kernel_name = "msda_fwd_winp";
+    return launch_forward_winp(value, shapes, lsi, loc, attn, d, out, stream);
+  }
+  if (variant == kWinL && !winl_forward_ok(d)) variant = lg3_ok(d) ? kLaneGroupL3 : kLaneGroup;
+  if (variant == kWinL) {
+    *kernel_name = "msda_fwd_winl";
+    return launch_forward_winl(value, shapes, lsi, loc, attn, d, out, stream);
+  }
   if (variant == kWin4 && !win4_forward_ok(d)) variant = lg3_ok(d) ? kLaneGroupL3 : kLaneGroup;
   if (variant == kWin4) {
     *kernel_name = "msda_fwd_win4";
@@ -617,11 +627,6 @@ int launch_forward<float>(int variant, const float* value, const int64_t* shapes
     return launch_forward_win2(value, shapes, lsi, loc, attn, d, out, stream);
   }
 #endif
-  if (variant == kWinL && !winl_forward_ok(d)) variant = lg3_ok(d) ? kLaneGroupL3 : kLaneGroup;
-  if (variant == kWinL) {
-    *kernel_name = "msda_fwd_winl";
-    return launch_forward_winl(value, shapes, lsi, loc, attn, d, out, stream);
-  }
   if (variant == kWin && !win_forward_ok(d)) variant = lg3_ok(d) ? kLaneGroupL3 : kLaneGroup;
   if (variant == kWin) {
     *kernel_name = "msda_fwd_win";
