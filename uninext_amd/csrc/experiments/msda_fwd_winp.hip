@@ -21,7 +21,8 @@
 //                    once for ANY sample positions.  Register set j accumulates piece j ^ t.
 //   work item      = (image, head, 8 x 16 tile of level-0 pixels + the pixels of levels 1..3 whose centres fall into the tile's
 //                    rectangle): msda_fwd_win's partition, windows (12x20 / 10x14 / 10x12 / 10x10 pixels, 76 KB) and placement
-//                    rule.  Waves 0..7 = the tile's rows (16 pairs each), waves 8..11 = up to 64 queries of levels 1..3.
+//                    rule, the latter from a SUBSAMPLE (see producer).  Waves 0..7 = the tile's rows (16 pairs each), waves 8..10 =
+//                    up to 48 queries of levels 1..3, wave 11 = the producer.
 //   pipeline       = iteration i of the persistent workgroup:   wait for the locations of item i + 1 and the windows of item i
 //                    (both requested one iteration ago) -> placement sums of item i + 1 -> THE barrier of the iteration ->
 //                    origins of item i + 1, its window DMA into the other set, the location loads of item i + 2 (all
@@ -38,14 +39,27 @@
 
 #include "../msda_common.hpp"
 
+#ifndef WINP_PRIO_REST
+#define WINP_PRIO_REST 2
+#endif
+#ifndef WINP_PRIO_MID
+#define WINP_PRIO_MID 1
+#endif
+#ifndef WINP_PMASK
+#define WINP_PMASK 15      // pyramid levels whose window DMA the producer issues (the consumers share the others)
+#endif
+#ifndef WINP_FETCH_AT
+#define WINP_FETCH_AT 0     // the next item's location loads are issued behind this sample of the gather
+#endif
 #ifndef WINP_RING
-#define WINP_RING 4     // LDS reads in flight per lane during the gather (4, 8 or 16; 8 spills at 168 registers)
+#define WINP_RING 8     // LDS reads in flight per lane during the gather (4, 8 or 16)
 #endif
 
 namespace msda {
 namespace {
 
-constexpr int kT = 768, kWaves = kT / 64, kQuads = kT / 4;      // 192 pairs per round
+constexpr int kT = 768, kWaves = kT / 64, kCons = kWaves - 1;       // 11 consumer waves + the producer
+constexpr int kRest0 = 48, kRestN = kCons * 16;                 // queries of levels 1..3 in round 0 (waves 8..10) / in a later round
 constexpr int kTH = 8, kTW = 16;                                // level-0 pairs of an item: waves 0..7, 16 pairs each
 constexpr int kWH[4] = {12, 10, 10, 10};
 constexpr int kWW[4] = {20, 14, 12, 10};                        // even: slot parity == column parity in every row
@@ -60,8 +74,8 @@ constexpr int kZeroOff = 2 * kSetBytes;                         // all-zero regi
 constexpr int kZeroBytes = kWW[0] * 128 + 256;                  // a bottom-row read lands at most one level-0 row further
 static_assert(kSetBytes % 256 == 0, "slot parity by address bit 7 in both sets and the zero region");
 struct Meta {
-  int part[2][8][4][4];                                         // [item parity][level-0 wave] per level: sum x0, sum y0, count, -
-  int org[2][4][4];                                             // [item parity] per level: window origin x, y; last near column / row
+  int geo[4][32];                                               // ring by item ordinal: [0..7] = image, level-0 xs, ys, nx, ny, e1, e2, nrest; [8 + 4 l ..] = xs, ys, nx, ny of level l
+  int org[4][4][4];                                             // ring by item ordinal, per level: window origin x, y; last near column / row
   int lvl[4][8];                                                // per level: H, W, first pixel, window rows, window columns
   int stat[4];
 };
@@ -106,6 +120,22 @@ __device__ __forceinline__ v2f sub_clamp01(v2f a, v2f b) {
 }
 
 template <int I> using IC = std::integral_constant<int, I>;
+
+// Phase timestamps (-DWINP_PROF; tools/winp_prof.py): every wave writes the 100 MHz real-time counter at the phase boundaries of
+// iteration kProfIter of its workgroup.
+#ifdef WINP_PROF
+constexpr int kProfBlocks = 256, kProfSlots = 16, kProfIter = 4;
+__device__ unsigned long long g_winp_prof[kProfBlocks * 12 * kProfSlots];
+#define WINP_STAMP(n_, i_)                                                                                       \
+  do {                                                                                                           \
+    if ((n_) == kProfIter && (threadIdx.x & 63) == 0) {                                                          \
+      const unsigned blk_ = blockIdx.y * gridDim.x + blockIdx.x;                                                 \
+      if (blk_ < (unsigned)kProfBlocks) g_winp_prof[(blk_ * 12 + (threadIdx.x >> 6)) * kProfSlots + (i_)] = __builtin_amdgcn_s_memrealtime(); \
+    }                                                                                                            \
+  } while (0)
+#else
+#define WINP_STAMP(n_, i_) do { } while (0)
+#endif
 
 // a lane's share of one work item: its query, and the locations / weights of its point on the four levels
 struct Lane {
@@ -166,12 +196,14 @@ msda_fwd_winp(const float* __restrict__ value, const int64_t* __restrict__ shape
   // per-image bases of an item (uniform: per-lane offsets stay 32-bit, S * M * 128 < 2^31)
   auto image_of = [&](int item) __attribute__((always_inline)) { return (int)(((float)item + 0.5f) * __builtin_amdgcn_rcpf((float)ntiles)); };
 
-  // ---- tile geometry of an item: lane k (of every quad) works out level k's query rectangle; readlane makes the level-0
-  // rectangle and the query counts scalar, the rectangles of levels 1..3 stay in lanes 1..3 (the queries of those levels fetch
-  // theirs with ds_bpermute) ----------------------------------------------------------------------------------------------
-  struct Geo { int vxs, vys, vnx, vW, vS; int xs0, ys0, nx0, ny0, e1, e2, nrest; };
-  auto geometry = [&](int item, int b) __attribute__((always_inline)) {
-    Geo g;
+  // ==== the producer's side (wave 11): tile geometry, placement from a subsample of the item's locations, window origins ====
+  // Tile geometry of an item: lane k works out level k's query rectangle; level-k pixels [f(t), f(t + 1)) with
+  // f(t) = ceil(t * T * n / n0 - 1/2) are the ones whose centre falls into tile t (msda_fwd_win's partition: any monotone f with
+  // f(0) = 0 is exact as long as every workgroup evaluates the same expression).  The record goes to mt.geo[slot]; the
+  // subsample -- points 1 and 2 of every level for 64 of the tile's 128 level-0 queries (a checkerboard) -- starts travelling.
+  struct Sub { f32x4 l[4]; int vxs, vys; };
+  auto produce = [&](int item, int slot, Sub& sb) __attribute__((always_inline)) -> int {
+    const int b = image_of(item);
     const int kq = lane & 3;
     const int4 lv4 = *reinterpret_cast<const int4*>(&mt.lvl[kq][0]);
     const int gW = lv4.y, gH = lv4.x;
@@ -182,17 +214,75 @@ msda_fwd_winp(const float* __restrict__ value, const int64_t* __restrict__ shape
     const int xe = tx == TX - 1 ? gW : min(max((int)ceilf((float)(tx + 1) * fxs - 0.5f), xs), gW);
     const int ys = min(max((int)ceilf((float)ty * fys - 0.5f), 0), gH);
     const int ye = ty == TY - 1 ? gH : min(max((int)ceilf((float)(ty + 1) * fys - 0.5f), ys), gH);
-    g.vxs = xs; g.vys = ys; g.vnx = xe - xs; g.vW = gW; g.vS = lv4.z;
+    sb.vxs = xs; sb.vys = ys;
     const int cnt = (xe - xs) * (ye - ys);
-    g.xs0 = __builtin_amdgcn_readlane(xs, 0); g.ys0 = __builtin_amdgcn_readlane(ys, 0);
-    g.nx0 = __builtin_amdgcn_readlane(xe - xs, 0); g.ny0 = __builtin_amdgcn_readlane(ye - ys, 0);
-    g.e1 = __builtin_amdgcn_readlane(cnt, 1);
-    g.e2 = g.e1 + __builtin_amdgcn_readlane(cnt, 2);
-    g.nrest = g.e2 + __builtin_amdgcn_readlane(cnt, 3);
-    return g;
+    const int xs0 = __builtin_amdgcn_readlane(xs, 0), ys0 = __builtin_amdgcn_readlane(ys, 0);
+    const int nx0 = __builtin_amdgcn_readlane(xe - xs, 0), ny0 = __builtin_amdgcn_readlane(ye - ys, 0);
+    const int e1 = __builtin_amdgcn_readlane(cnt, 1), e2 = e1 + __builtin_amdgcn_readlane(cnt, 2), nrest = e2 + __builtin_amdgcn_readlane(cnt, 3);
+    if (lane < 4) *reinterpret_cast<int4*>(&mt.geo[slot][8 + 4 * kq]) = make_int4(xs, ys, xe - xs, ye - ys);
+    if (lane == 0) {
+      *reinterpret_cast<int4*>(&mt.geo[slot][0]) = make_int4(b, xs0, ys0, nx0);
+      *reinterpret_cast<int4*>(&mt.geo[slot][4]) = make_int4(ny0, e1, e2, nrest);
+    }
+    const int row = lane >> 3, col = 2 * (lane & 7) + (row & 1);
+    const uint32_t q = (uint32_t)(lvS[0] + (ys0 + row) * lvW[0] + xs0 + col);
+    const bool live = col < nx0 && row < ny0 && q < (uint32_t)d.Lq;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) sb.l[l] = f32x4{-4.f, -4.f, -4.f, -4.f};   // out of range on every level
+    if (live) {
+      const float* lp = loc + (int64_t)b * d.Lq * M * 32 + (mad_u24(q, (uint32_t)M, (uint32_t)m) * 32u + 2u);   // point 1 of level 0
+#pragma unroll
+      for (int l = 0; l < 4; ++l) {
+        const msda::f32x2 p1 = *reinterpret_cast<const msda::f32x2*>(lp + 8 * l), p2 = *reinterpret_cast<const msda::f32x2*>(lp + 8 * l + 2);
+        sb.l[l] = f32x4{p1[0], p1[1], p2[0], p2[1]};
+      }
+    }
+    return b;
+  };
+  // window origins of an item from its subsample: mean top-left corner of the in-range samples, per level -> mt.org[slot]
+  auto finish = [&](const Sub& sb, int slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      const v2f fWH = {fW[l], fH[l]};
+      float ax = 0.f, ay = 0.f;
+      int an = 0;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const v2f xy = __builtin_elementwise_fma(p ? v2f{sb.l[l][2], sb.l[l][3]} : v2f{sb.l[l][0], sb.l[l][1]}, fWH, v2f{-0.5f, -0.5f});
+        const bool inr = (xy.y > -1.f) && (xy.x > -1.f) && (xy.y < fWH.y) && (xy.x < fWH.x);
+        ax += inr ? floorf(xy.x) : 0.f;                       // small integers: float sums are exact
+        ay += inr ? floorf(xy.y) : 0.f;
+        an += __builtin_popcountll(__builtin_amdgcn_ballot_w64(inr));
+      }
+      const float sx = wave_total(ax), sy = wave_total(ay);   // lane 63
+      int myOx = __builtin_amdgcn_readlane(sb.vxs, l) - 3, myOy = __builtin_amdgcn_readlane(sb.vys, l) - 3;
+      if (an > 0) {
+        const float inv = __builtin_amdgcn_rcpf((float)an);
+        myOx = (int)floorf(sx * inv + 0.5f) - (kWW[l] - 2) / 2;
+        myOy = (int)floorf(sy * inv + 0.5f) - (kWH[l] - 2) / 2;
+      }
+      myOx = max(-1, min(myOx, lvW[l] + 1 - kWW[l]));
+      myOy = max(-1, min(myOy, lvH[l] + 1 - kWH[l]));
+      // a level smaller than its window: top-left corners past the last in-range one are not "near"
+      const int cxmax = min(myOx + kWW[l] - 2, lvW[l] - 1) - myOx, rymax = min(myOy + kWH[l] - 2, lvH[l] - 1) - myOy;
+      if (lane == 63) *reinterpret_cast<int4*>(&mt.org[slot][l][0]) = make_int4(myOx, myOy, cxmax, rymax);
+    }
+  };
+
+  // ==== the consumers' side (waves 0..10) =======================================================================================
+  // an item's record, as scalars
+  struct Hdr { int b, xs0, ys0, nx0, ny0, e1, e2, nrest; };
+  auto header = [&](int slot) __attribute__((always_inline)) {
+    const int4 h0 = *reinterpret_cast<const int4*>(&mt.geo[slot][0]), h1 = *reinterpret_cast<const int4*>(&mt.geo[slot][4]);
+    Hdr h;
+    h.b = __builtin_amdgcn_readfirstlane(h0.x); h.xs0 = __builtin_amdgcn_readfirstlane(h0.y);
+    h.ys0 = __builtin_amdgcn_readfirstlane(h0.z); h.nx0 = __builtin_amdgcn_readfirstlane(h0.w);
+    h.ny0 = __builtin_amdgcn_readfirstlane(h1.x); h.e1 = __builtin_amdgcn_readfirstlane(h1.y);
+    h.e2 = __builtin_amdgcn_readfirstlane(h1.z); h.nrest = __builtin_amdgcn_readfirstlane(h1.w);
+    return h;
   };
   // the lane's query in round `rnd` of an item, and the loads of its locations / weights (asynchronous: nothing waits here)
-  auto fetch = [&](const Geo& g, int b, int rnd, Lane& ln) __attribute__((always_inline)) {
+  auto fetch = [&](const Hdr& g, int slot, int rnd, Lane& ln) __attribute__((always_inline)) {
     bool live;
     uint32_t qidx;
     if (rnd == 0 && wv < 8) {                                // wave-uniform: the tile's row wv
@@ -200,17 +290,15 @@ msda_fwd_winp(const float* __restrict__ value, const int64_t* __restrict__ shape
       live = col < g.nx0 && wv < g.ny0;
       qidx = (uint32_t)(lvS[0] + (g.ys0 + wv) * lvW[0] + g.xs0 + col);
     } else {
-      const int ri = (rnd == 0 ? (wv - 8) * 16 : 64 + (rnd - 1) * kQuads + wv * 16) + (lane >> 2);
+      const int ri = (rnd == 0 ? (wv - 8) * 16 : kRest0 + (rnd - 1) * kRestN + wv * 16) + (lane >> 2);
       live = ri < g.nrest;
       const bool c1 = ri >= g.e1, c2 = ri >= g.e2;
       const int ql = 1 + (c1 ? 1 : 0) + (c2 ? 1 : 0);
       const int j = ri - (c2 ? g.e2 : c1 ? g.e1 : 0);
-      const int src = ((lane & ~3) | ql) << 2;               // lane ql of this quad holds level ql's rectangle
-      const int nx = __builtin_amdgcn_ds_bpermute(src, g.vnx), xs = __builtin_amdgcn_ds_bpermute(src, g.vxs);
-      const int ys = __builtin_amdgcn_ds_bpermute(src, g.vys), Wq = __builtin_amdgcn_ds_bpermute(src, g.vW);
-      const int Sq = __builtin_amdgcn_ds_bpermute(src, g.vS);
-      const int yy = (int)(((float)j + 0.5f) * __builtin_amdgcn_rcpf((float)max(nx, 1)));
-      qidx = (uint32_t)(Sq + (ys + yy) * Wq + xs + (j - yy * nx));
+      const int4 rc = *reinterpret_cast<const int4*>(&mt.geo[slot][8 + 4 * ql]);   // xs, ys, nx of the query's level
+      const int2 ws = *reinterpret_cast<const int2*>(&mt.lvl[ql][1]);               // W, first pixel
+      const int yy = (int)(((float)j + 0.5f) * __builtin_amdgcn_rcpf((float)max(rc.z, 1)));
+      qidx = (uint32_t)(ws.y + (rc.y + yy) * ws.x + rc.x + (j - yy * rc.z));
     }
     live = live && qidx < (uint32_t)d.Lq;                   // (shapes whose pixel count exceeds num_query: never outside the tensors)
     if (!live) qidx = 0u;
@@ -228,70 +316,27 @@ msda_fwd_winp(const float* __restrict__ value, const int64_t* __restrict__ shape
 #else
     if (live) {
 #endif
-      const int64_t pair_img = (int64_t)b * d.Lq * M;
+      const int64_t pair_img = (int64_t)g.b * d.Lq * M;
       const msda::f32x2* lp = reinterpret_cast<const msda::f32x2*>(loc + pair_img * 32 + (ln.pair * 32u + 2u * pt));
       const float* ap = attn + pair_img * 16 + (ln.pair * 16u + pt);
 #pragma unroll
-#ifdef WINP_LOADS_NT
-      for (int l = 0; l < 4; ++l) ln.lc[l] = __builtin_nontemporal_load(lp + 4 * l);
-#pragma unroll
-      for (int l = 0; l < 4; ++l) ln.at[l] = __builtin_nontemporal_load(ap + 4 * l);
-#else
       for (int l = 0; l < 4; ++l) ln.lc[l] = lp[4 * l];
 #pragma unroll
       for (int l = 0; l < 4; ++l) ln.at[l] = ap[4 * l];
-#endif
     }
-  };
-  // placement sums of an item: the in-range top-left corners of the samples of its level-0 queries, per level; one int4 per
-  // (wave, level) into mt.part[parity] (waves 0..7 only)
-  auto place = [&](const Lane& ln, int parity) __attribute__((always_inline)) {
-    int tot[4][3];
-#pragma unroll
-    for (int l = 0; l < 4; ++l) {
-      const v2f fWH = {fW[l], fH[l]};
-      const v2f xy = __builtin_elementwise_fma(v2f{ln.lc[l][0], ln.lc[l][1]}, fWH, v2f{-0.5f, -0.5f});
-      const bool inr = (xy.y > -1.f) && (xy.x > -1.f) && (xy.y < fWH.y) && (xy.x < fWH.x);
-      tot[l][0] = (int)wave_total(inr ? floorf(xy.x) : 0.f);   // small integers: float sums are exact
-      tot[l][1] = (int)wave_total(inr ? floorf(xy.y) : 0.f);
-      tot[l][2] = __builtin_popcountll(__builtin_amdgcn_ballot_w64(inr));
-    }
-    if (lane == 63) {
-#pragma unroll
-      for (int l = 0; l < 4; ++l) *reinterpret_cast<int4*>(&mt.part[parity][wv][l][0]) = make_int4(tot[l][0], tot[l][1], tot[l][2], 0);
-    }
-  };
-  // window origins of an item from its placement sums (after the barrier): lane k works out level k; returned per lane
-  auto origins = [&](const Geo& g, int parity, int& myOx, int& myOy) __attribute__((always_inline)) {
-    const int k = lane & 3;
-    int4 sm = *reinterpret_cast<const int4*>(&mt.part[parity][0][k][0]);
-#pragma unroll
-    for (int w = 1; w < 8; ++w) {
-      const int4 t = *reinterpret_cast<const int4*>(&mt.part[parity][w][k][0]);
-      sm.x += t.x; sm.y += t.y; sm.z += t.z;
-    }
-    const int4 lv4 = *reinterpret_cast<const int4*>(&mt.lvl[k][0]);
-    const int myH = lv4.x, myW = lv4.y, myWH = lv4.w, myWW = mt.lvl[k][4];
-    myOx = g.vxs - 3; myOy = g.vys - 3;
-    if (sm.z > 0) {   // v_rcp_f32: every lane of the workgroup evaluates the same expression on the same sums
-      const float inv = __builtin_amdgcn_rcpf((float)sm.z);
-      myOx = (int)floorf((float)sm.x * inv + 0.5f) - (myWW - 2) / 2;
-      myOy = (int)floorf((float)sm.y * inv + 0.5f) - (myWH - 2) / 2;
-    }
-    myOx = max(-1, min(myOx, myW + 1 - myWW));
-    myOy = max(-1, min(myOy, myH + 1 - myWH));
-    // a level smaller than its window: top-left corners past the last in-range one are not "near"
-    const int cxmax = min(myOx + myWW - 2, myW - 1) - myOx, rymax = min(myOy + myWH - 2, myH - 1) - myOy;
-    if (tid < 4) *reinterpret_cast<int4*>(&mt.org[parity][k][0]) = make_int4(myOx, myOy, cxmax, rymax);   // read at the item's gather, a barrier later
   };
   // ---- stage an item's four windows into set `parity`: LDS-DMA, one instruction = 8 consecutive window slots (1 KB) of ONE
   // level.  The wave's number is a compile-time constant of each copy, so a chunk's window row / column / wrap position are
   // constants and its offset is (invariant per-lane part) + (scalar base of the chunk's row), plus one select where the chunk
   // wraps into the next window row ---------------------------------------------------------------------------------------
-  auto stage = [&](int b, int parity, int myOx, int myOy) __attribute__((always_inline)) {
+  auto stage = [&](int b, int parity, int slot, auto mtag) __attribute__((always_inline)) {
+    constexpr int MASK = decltype(mtag)::value;              // levels staged by this call
     int ogx[4], ogy[4];
 #pragma unroll
-    for (int l = 0; l < 4; ++l) { ogx[l] = __builtin_amdgcn_readlane(myOx, l); ogy[l] = __builtin_amdgcn_readlane(myOy, l); }
+    for (int l = 0; l < 4; ++l) {
+      const int2 og = *reinterpret_cast<const int2*>(&mt.org[slot][l][0]);
+      ogx[l] = __builtin_amdgcn_readfirstlane(og.x); ogy[l] = __builtin_amdgcn_readfirstlane(og.y);
+    }
     const __amdgpu_buffer_rsrc_t vsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(value) + (int64_t)b * d.S * M * 32, 0, (int)((uint32_t)d.S * pixB), 0x00020000);
     // (nothing below may be hoisted out of the item loop: as loop invariants the per-chunk scalars do not fit the scalar
@@ -306,7 +351,8 @@ msda_fwd_winp(const float* __restrict__ value, const int64_t* __restrict__ shape
     auto stage_level = [&](auto wtag, auto ltag) __attribute__((always_inline)) {
       constexpr int WV = decltype(wtag)::value, LV = decltype(ltag)::value;
       constexpr int WW = kWW[LV], C0 = kBase[LV] / 8, C1 = kBase[LV + 1] / 8;
-      constexpr int I0 = C0 + ((WV - C0) % kWaves + kWaves) % kWaves;   // this wave's first chunk of the level
+      constexpr int NW = WV < 0 ? 1 : kCons;                   // WV < 0: the producer, every chunk; else consumer WV's share
+      constexpr int I0 = WV < 0 ? C0 : C0 + ((WV - C0) % kCons + kCons) % kCons;
       const int Hs = lvH[LV], xS = ogx[LV] + lvS[LV], oy = ogy[LV], ox = ogx[LV];
       int Ws = lvW[LV];
       asm volatile("" : "+s"(Ws));
@@ -314,7 +360,7 @@ msda_fwd_winp(const float* __restrict__ value, const int64_t* __restrict__ shape
       if (Ws + 2 >= WW) {                                  // at most ONE window column outside the image on either side
         const int border = (int)((uint32_t)ox >> 31) | (int)((uint32_t)(Ws - ox - WW) >> 31);
 #pragma unroll
-        for (int i = I0; i < C1; i += kWaves) {
+        for (int i = I0; i < C1; i += NW) {
           const int rel0 = 8 * (i - C0);
           const int r0 = rel0 / WW, c0 = rel0 - r0 * WW;   // constants after unrolling
           const int thr = WW - c0;                          // lanes with sub >= thr sit in window row r0 + 1
@@ -340,7 +386,7 @@ msda_fwd_winp(const float* __restrict__ value, const int64_t* __restrict__ shape
       }
       // (levels narrower than their window: per-lane row / column / inside-the-image arithmetic for every DMA instruction)
 #pragma unroll
-      for (int i = I0; i < C1; i += kWaves) {
+      for (int i = I0; i < C1; i += NW) {
         const int rel = 8 * (i - C0) + (int)vsub;           // slot of this lane in the level's window
         const int r = (int)(((float)rel + 0.5f) * (1.f / WW)), c = rel - r * WW;
         const int y = oy + r;
@@ -354,10 +400,14 @@ msda_fwd_winp(const float* __restrict__ value, const int64_t* __restrict__ shape
       }
     };
     auto stage_all = [&](auto wtag) __attribute__((always_inline)) {
-      stage_level(wtag, IC<0>{}); stage_level(wtag, IC<1>{}); stage_level(wtag, IC<2>{}); stage_level(wtag, IC<3>{});
+      if (MASK & 1) stage_level(wtag, IC<0>{});
+      if (MASK & 2) stage_level(wtag, IC<1>{});
+      if (MASK & 4) stage_level(wtag, IC<2>{});
+      if (MASK & 8) stage_level(wtag, IC<3>{});
     };
 #ifndef WINP_NODMA
-    switch (wv) {
+    if (wv == kCons) stage_all(IC<-1>{});
+    else switch (wv) {
       case 0: stage_all(IC<0>{}); break;
       case 1: stage_all(IC<1>{}); break;
       case 2: stage_all(IC<2>{}); break;
@@ -368,19 +418,20 @@ msda_fwd_winp(const float* __restrict__ value, const int64_t* __restrict__ shape
       case 7: stage_all(IC<7>{}); break;
       case 8: stage_all(IC<8>{}); break;
       case 9: stage_all(IC<9>{}); break;
-      case 10: stage_all(IC<10>{}); break;
-      default: stage_all(IC<11>{}); break;
+      default: stage_all(IC<10>{}); break;
     }
 #endif
   };
 
   // ---- the gather of one round of an item (lane data `ln`) out of window set `parity`, far samples, the quad's sum, the
   // stores -------------------------------------------------------------------------------------------------------------------
-  auto gather = [&](const Lane& ln, int b, int parity) __attribute__((always_inline)) {
+  int prof_n = -1;                                          // (profiling build: the iteration being stamped)
+  (void)prof_n;
+  auto gather = [&](const Lane& ln, int b, int parity, int slot, auto&& hook) __attribute__((always_inline)) {
     int ogx[4], ogy[4], cxm[4], rym[4];                      // window origin, last near column / row: scalars
 #pragma unroll
     for (int l = 0; l < 4; ++l) {
-      const int4 og = *reinterpret_cast<const int4*>(&mt.org[parity][l][0]);
+      const int4 og = *reinterpret_cast<const int4*>(&mt.org[slot][l][0]);
       ogx[l] = __builtin_amdgcn_readfirstlane(og.x); ogy[l] = __builtin_amdgcn_readfirstlane(og.y);
       cxm[l] = __builtin_amdgcn_readfirstlane(og.z); rym[l] = __builtin_amdgcn_readfirstlane(og.w);
     }
@@ -479,11 +530,16 @@ msda_fwd_winp(const float* __restrict__ value, const int64_t* __restrict__ shape
 #ifndef WINP_NOPASS
     prep(IC<0>{});
     issue_part(IC<0>{}, pF);
-    sample(IC<0>{}, IC<1>{}, true);
-    sample(IC<1>{}, IC<2>{}, true);
-    sample(IC<2>{}, IC<3>{}, true);
-    sample(IC<3>{}, IC<3>{}, false);
+    // (the hooks: this wave's share of the NEXT item's location loads and window DMA, issued between the samples so that the
+    // texture path works while the LDS does)
+    sample(IC<0>{}, IC<1>{}, true); hook(IC<0>{});
+    sample(IC<1>{}, IC<2>{}, true); hook(IC<1>{});
+    sample(IC<2>{}, IC<3>{}, true); hook(IC<2>{});
+    sample(IC<3>{}, IC<3>{}, false); hook(IC<3>{});
+#else
+    hook(IC<0>{}); hook(IC<1>{}); hook(IC<2>{}); hook(IC<3>{});
 #endif
+    WINP_STAMP(prof_n, 5);
 
     // ---- the quad's four partial sums meet: register set j of this lane holds piece j ^ t; the lane whose number differs in bit
     // 0 / bit 1 holds the same piece in set j ^ 1 / j ^ 2.  Each lane finishes the sets 0 and 4: the quad stores 2 x 64 contiguous
@@ -556,6 +612,7 @@ msda_fwd_winp(const float* __restrict__ value, const int64_t* __restrict__ shape
       }
     }
 
+    WINP_STAMP(prof_n, 6);
     if (ln.live) {
       char* op = reinterpret_cast<char*>(out + (int64_t)b * d.Lq * M * 32) + (size_t)ln.pair * 128u;
 #ifdef WINP_NOSTORE
@@ -570,69 +627,98 @@ msda_fwd_winp(const float* __restrict__ value, const int64_t* __restrict__ shape
   };
 
   // =========================================================================================================================
-  // the pipeline.  cur / nxt / nx2 = lane data of the items i, i + 1, i + 2 of this workgroup
-  const int first = kk;
-  Lane cur, nxt, nx2;
-  Geo gn, g2;                                               // geometry of items i + 1, i + 2
-  int bn, b2;
-  // fill: item `first` goes through loads -> placement -> barrier -> origins -> DMA with nothing to hide behind
-  {
-    const int b0 = image_of(first);
-    const Geo g0 = geometry(first, b0);
-    fetch(g0, b0, 0, cur);
-    if (wv < 8) place(cur, 0);
-    __syncthreads();
-    int ox, oy;
-    origins(g0, 0, ox, oy);
-    stage(b0, 0, ox, oy);
-    gn = g0; bn = b0;                                       // (placeholders when there is no second item)
-    nxt = cur;
-    if (first + K < nitems) {
-      bn = image_of(first + K);
-      gn = geometry(first + K, bn);
-      fetch(gn, bn, 0, nxt);
-    }
-    // the geometry of item `first` is needed once more for its later rounds (odd pyramids): kept in g2 / b2 until the loop rotates
-    g2 = g0; b2 = b0;
-  }
-  Geo gc = g2;                                              // geometry of the CURRENT item (later rounds only)
-  int bc = b2;
-  for (int item = first, it = 0; item < nitems; item += K, ++it) {
-    const int par = it & 1;
-    const bool has1 = item + K < nitems, has2 = item + 2 * K < nitems;
-    // a. placement sums of item i + 1 (its locations were requested one iteration ago); the windows of item i have landed
-    if (has1 && wv < 8) place(nxt, par ^ 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's share of item i's windows (and everything older)
-    __syncthreads();                                         // THE barrier of the iteration
-    // b. origins + window DMA of item i + 1 into the other set (whose last reader, the gather of item i - 1, is behind the barrier)
-    if (has1) {
-      int ox, oy;
-      origins(gn, par ^ 1, ox, oy);
-      stage(bn, par ^ 1, ox, oy);
-    }
-    // c. the locations of item i + 2 start travelling
-    nx2 = nxt; g2 = gn; b2 = bn;
-    if (has2) {
-      b2 = image_of(item + 2 * K);
-      g2 = geometry(item + 2 * K, b2);
-      fetch(g2, b2, 0, nx2);
-    }
-    // e. gather + stores of item i
-    const bool busy = wv < 8 || (wv - 8) * 16 < gc.nrest;   // a wave without a query skips the gather
-    if (busy) gather(cur, bc, par);
-    // (odd pyramids: more than 64 queries of levels 1..3 in a tile -- further rounds on the same windows, not pipelined)
-    if (gc.nrest > 64) {
-      const int nrounds = 1 + (gc.nrest - 64 + kQuads - 1) / kQuads;
-      for (int rnd = 1; rnd < nrounds; ++rnd) {
-        if (64 + (rnd - 1) * kQuads + wv * 16 >= gc.nrest) continue;
-        Lane ex;
-        fetch(gc, bc, rnd, ex);
-        gather(ex, bc, par);
+  // the pipeline.  Item ordinal n of this workgroup = item kk + n K.  Iteration n (behind its barrier):
+  //   producer   finish(n + 2): origins from the subsample requested one iteration ago;  produce(n + 3): geometry + subsample loads
+  //   consumers  window DMA of item n + 1 (origins finished one iteration ago) into the other set;  location loads of item n + 2;
+  //              gather + stores of item n (windows requested one iteration ago, locations two)
+  // Rings of 4 in LDS (mt.geo, mt.org): a slot is rewritten three iterations after its last reader.
+  auto exists = [&](int n) __attribute__((always_inline)) { return kk + n * K < nitems; };
+  if (wv == kCons) {
+    // ---- producer -------------------------------------------------------------------------------------------------------
+    Sub s0, s1;
+    const int b0 = produce(kk, 0, s0);
+    if (exists(1)) (void)produce(kk + K, 1, s1);
+    finish(s0, 0);
+    if (exists(1)) finish(s1, 1);
+    if (exists(2)) (void)produce(kk + 2 * K, 2, s1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the origins just written are read back as scalars by stage)
+    stage(b0, 0, 0, IC<15>{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                         // prologue barrier: geo(0..2), org(0..1), the windows of item 0
+    for (int n = 0; exists(n); ++n) {
+      WINP_STAMP(n, 0);
+      __syncthreads();                                       // the barrier of iteration n: the gather of item n - 1 is over
+      WINP_STAMP(n, 1);
+      if (exists(n + 1)) {
+        const Hdr h1 = header((n + 1) & 3);
+        stage(h1.b, (n + 1) & 1, (n + 1) & 3, IC<WINP_PMASK>{});   // into the set the gather of item n - 1 has just left
       }
+      WINP_STAMP(n, 2);
+      if (exists(n + 2)) finish(s1, (n + 2) & 3);
+      WINP_STAMP(n, 3);
+      if (exists(n + 3)) (void)produce(kk + (n + 3) * K, (n + 3) & 3, s1);
+      WINP_STAMP(n, 4);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the windows of item n + 1 have landed before the next barrier
+      WINP_STAMP(n, 5);
     }
-    cur = nxt; nxt = nx2; gc = gn; bc = bn; gn = g2; bn = b2;
+  } else {
+    // ---- consumers --------------------------------------------------------------------------------------------------------
+    if (wv >= 8) __builtin_amdgcn_s_setprio(WINP_PRIO_REST);  // the youngest waves of their SIMDs get the leftover issue slots otherwise
+    else if (wv >= 4) __builtin_amdgcn_s_setprio(WINP_PRIO_MID);
+    Lane cur, nxt;
+    __syncthreads();                                         // prologue barrier
+    {
+      const Hdr h0 = header(0);
+      fetch(h0, 0, 0, cur);
+      nxt = cur;
+    }
+    auto nohook = [&](auto) __attribute__((always_inline)) {};
+    for (int n = 0; exists(n); ++n) {
+      const int par = n & 1;
+      WINP_STAMP(n, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the locations of item n (its windows are the producer's business)
+      WINP_STAMP(n, 1);
+      __syncthreads();                                       // the barrier of iteration n
+      WINP_STAMP(n, 2);
+      const bool more = exists(n + 1);
+      const int s1 = (n + 1) & 3;
+      Hdr h1 = header(more ? s1 : (n & 3));
+      // the location loads of item n + 1 travel under the gather
+      auto hook = [&](auto ktag) __attribute__((always_inline)) {
+        constexpr int KS = decltype(ktag)::value;
+        if (more && KS == WINP_FETCH_AT) fetch(h1, s1, 0, nxt);
+        // the consumers' share of item n + 1's window DMA (the levels the producer leaves to them; its origins were finished
+        // one barrier ago: WINP_PMASK != 15 needs the producer one item further ahead -- see the producer's loop)
+        if (more && KS == 1 && (15 & ~WINP_PMASK) != 0) stage(h1.b, par ^ 1, s1, IC<(15 & ~WINP_PMASK)>{});
+      };
+      const Hdr hc = header(n & 3);
+      const bool busy = wv < 8 || (wv - 8) * 16 < hc.nrest;  // a wave without a query skips the gather
+      prof_n = n;
+      if (busy) gather(cur, hc.b, par, n & 3, hook);
+      else { hook(IC<0>{}); hook(IC<1>{}); hook(IC<2>{}); hook(IC<3>{}); }
+      prof_n = -1;
+      WINP_STAMP(n, 8);
+      // (odd pyramids: more than 48 queries of levels 1..3 in a tile -- further rounds on the same windows, not pipelined)
+      if (hc.nrest > kRest0) {
+        const int nrounds = 1 + (hc.nrest - kRest0 + kRestN - 1) / kRestN;
+        for (int rnd = 1; rnd < nrounds; ++rnd) {
+          if (kRest0 + (rnd - 1) * kRestN + wv * 16 >= hc.nrest) continue;
+          Lane ex;
+          fetch(hc, n & 3, rnd, ex);
+          gather(ex, hc.b, par, n & 3, nohook);
+        }
+      }
+      cur = nxt;
+    }
   }
 }
+
+#ifdef WINP_PROF
+extern "C" int msda_debug_read_prof_winp(void* dst, int nblocks) {
+  if (nblocks > kProfBlocks) nblocks = kProfBlocks;
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_winp_prof), (size_t)nblocks * 12 * kProfSlots * 8, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 bool winp_forward_ok(const Dims& d) { return win_forward_ok(d); }
 
