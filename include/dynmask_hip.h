@@ -60,9 +60,11 @@ int aligned_bilinear_hip_f32(const float* in, int n, int h, int w, int factor, f
  * dynamic_mask_with_coords under autograd).  Same inputs as the forward plus
  *   grad_logits  [n_inst_all, H, W]     gradient of the loss with respect to out_logits
  * and the gradients, every element written (no accumulation, no float atomics: results are bitwise repeatable):
- *   grad_feats   [batch, 8, H, W]       sum over the image's instances (zeros for an image without instances)
- *   grad_params  [n_inst_all, 169|153]  sum over the pixels, in the layout of `params`
- *   grad_xy      [n_inst_all, 2] or NULL  gradient with respect to inst_xy (zeros with rel_coord == 0)
+ *   grad_feats   [batch, 8, H, W] or NULL       sum over the image's instances (zeros for an image without instances)
+ *   grad_params  [n_inst_all, 169|153] or NULL  sum over the pixels, in the layout of `params`
+ *   grad_xy      [n_inst_all, 2] or NULL        gradient with respect to inst_xy (zeros with rel_coord == 0); needs grad_params
+ * A NULL gradient is not computed: grad_feats == NULL skips the pixel-major kernels, grad_params == NULL (with grad_xy == NULL)
+ * the instance-major ones and the workspace (frozen mask features / detached parameters; round 6).
  * workspace: device memory of at least dynmask_hip_backward_workspace_bytes(n_inst_all, H, W) bytes (partial sums of the
  * pixel slices, dynmask_hip_backward_parts of them per instance), contents undefined before and after; borrowed for the call
  * in stream order.  At most DYNMASK_HIP_BWD_MAX_BATCH images per call (DYNMASK_ERR_UNSUPPORTED beyond).

@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define MSDA_HIP_ABI_VERSION 1
+#define MSDA_HIP_ABI_VERSION 2
 
 #define MSDA_ERR_NULL_POINTER (-1)
 #define MSDA_ERR_BAD_DIMS (-2)      /* a dimension <= 0 (except batch/num_query == 0, which is a no-op) */

@@ -54,7 +54,7 @@ def test_dynmask_header_symbols_are_exported(lib):
 
 def test_abi_version_and_variant_table(lib):
     from uninext_amd import _lib
-    assert lib.msda_hip_abi_version() == _lib.ABI_VERSION == 1
+    assert lib.msda_hip_abi_version() == _lib.ABI_VERSION == 2
     # numbers are stable; the default build names the kernels it does not carry "exp:..." and refuses to select them
     full = ["auto", "msda_fwd_generic", "msda_fwd_lanegroup", "msda_fwd_tiled", "msda_fwd_tiled_l0", "msda_fwd_tiled_l0big",
             "msda_fwd_lgcl", "msda_fwd_lg3", "msda_fwd_lgp", "msda_fwd_win", "msda_fwd_win2", "msda_fwd_win3", "msda_fwd_win4",
@@ -122,7 +122,8 @@ def test_environment_switches_are_the_documented_ones():
     the environment; no "wrong results" timing macro is left in a shipped translation unit."""
     import re
     allowed = {"MSDA_HIP_LIB", "MSDA_HIP_FWD_VARIANT", "MSDA_HIP_BWD_VARIANT", "MSDA_HIP_FWD_ADAPTIVE", "MSDA_HIP_STRICT_DEVICE",
-               "MSDA_HOST_THREADS", "MSDA_HIP_TORCH_WORKSPACE", "UNINEXT_AMD_SPLIT_BF16", "UNINEXT_AMD_NO_FUSED"}
+               "MSDA_HOST_THREADS", "MSDA_HIP_TORCH_WORKSPACE", "UNINEXT_AMD_SPLIT_BF16", "UNINEXT_AMD_NO_FUSED",
+               "UNINEXT_AMD_NO_FUSED_TRAINING"}
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     seen = set()
     pkg = os.path.join(ROOT, "uninext_amd")

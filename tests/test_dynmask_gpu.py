@@ -181,3 +181,26 @@ def test_hip_gradients_with_an_image_without_instances_and_detached_inputs():
     out.square().sum().backward()
     assert torch.isfinite(feats.grad).all() and float(feats.grad[1].abs().max()) == 0.0 and float(feats.grad[0].abs().max()) > 0
     assert torch.isfinite(params.grad).all() and ref.grad is None
+
+
+def test_hip_gradients_of_one_input_alone_equal_those_of_the_full_backward():
+    """Round 6: frozen mask features or detached parameters -- the backward launches only the kernel family the wanted
+    gradient needs (NULL grad_feats / grad_params in the C ABI), and what it returns is bitwise what the full backward returns."""
+    g = torch.Generator().manual_seed(33)
+    feats0 = torch.randn(2, 8, 12, 20, generator=g).to(DEV)
+    ref0 = (torch.rand(1, 6, 2, generator=g) * 90).to(DEV)
+    params0 = (torch.randn(1, 6, 169, generator=g) * 0.3).to(DEV)
+
+    def run(need):
+        t = [x.clone().requires_grad_(n) for x, n in zip((feats0, ref0, params0), need)]
+        out = mask_head.dynamic_mask_with_coords(t[0], t[1], t[2], [4, 2], 8)
+        out.square().sum().backward()
+        return [x.grad for x in t]
+
+    full = run((True, True, True))
+    for need in ((True, False, False), (False, False, True), (False, True, False), (True, False, True)):
+        got = run(need)
+        for a, b, n in zip(got, full, need):
+            assert (a is None) == (not n)
+            if n:
+                assert torch.equal(a, b), need

@@ -233,6 +233,18 @@ def test_derived_call_sites_for_callers_that_pass_none():
         for i in range(1, 40):                                    # more calls than slots: wraps around
             ctx(sh, locs[0])
         assert lib.calls[-1][0] == ext.AUTO_SITE_BASE + 39 % ext.AUTO_SITES
+        # a shapes tensor built under torch.inference_mode() has no version counter (`_version` raises on it) -- the
+        # bare operator / the reference's unmodified module is called exactly like that by an inference script
+        with torch.inference_mode():
+            shi = torch.zeros(4, 2, dtype=torch.long)
+            li = torch.zeros(8)
+            ctx(shi, li)
+            ctx(shi, li)
+        assert [c[0] for c in lib.calls[-2:]] == [ext.AUTO_SITE_BASE, ext.AUTO_SITE_BASE + 1]
+        # ... and the backward calls that found no forward are counted (they are correct, but take the history-free kernel)
+        before = ext.unmatched_backward_calls()
+        ctx(sh, torch.zeros(7), backward=True)
+        assert ext.unmatched_backward_calls() == before + 1
     finally:
         ext._geometry_checked = real
         ext.reset_auto_sites()

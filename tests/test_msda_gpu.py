@@ -687,6 +687,24 @@ def test_module_under_inference_mode(dev, api, split_bf16_paths):
     assert float((a - c).abs().max()) < 1e-6
 
 
+def test_bare_operator_under_inference_mode_without_a_call_site(dev):
+    """INTEGRATION option A -- the operator called with no call_site() block (the reference's unmodified module
+    does that) on an encoder-shaped fp32 call whose shapes tensor was built under torch.inference_mode().  The derived-site
+    logic must not touch `_version` of an inference tensor; results equal those under no_grad."""
+    from uninext_amd import ext, workloads
+    levels = ((40, 53), (20, 27), (10, 14), (5, 7))          # S = 2835 >= 1024: takes a call context
+    x = workloads.make_inputs("encoder", batch=1, levels=levels, seed=5, device=dev)
+    with torch.no_grad():
+        want = ext.ms_deform_attn_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], 64)
+    with torch.inference_mode():
+        sh = torch.as_tensor(levels, dtype=torch.long, device=dev)
+        lsi = torch.cat((sh.new_zeros((1,)), sh.prod(1).cumsum(0)[:-1]))
+        outs = [ext.ms_deform_attn_forward(x["value"], sh, lsi, x["loc"], x["attn"], 64) for _ in range(4)]
+    assert ext.last_call_site() >= ext.AUTO_SITE_BASE
+    for o in outs:
+        assert float((o - want).abs().max()) < 1e-5
+
+
 # ------------------------------------------------------------------------------------------------
 # training-side prologue (include/msda_hip.h: msda_hip_prologue_f32 / msda_hip_prologue_backward_f32, MSDeformAttnFusedFunction)
 

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MSDA_HIP_LIB points the binding at another build of the SAME library (A/B builds of experimental kernels)
 LIB_PATH = os.environ.get("MSDA_HIP_LIB") or os.path.join(_HERE, "lib", "libmsda_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2   # 2 (round 6): dynmask backward exports, msda_hip_reset_call_site, OTA flags as a bit field (bit 1 = degenerate box) and status bit 2, msda_bwd_regions accumulates -- all of round 5, which had left the number at 1
 EXPORTS = (
     "msda_hip_abi_version", "msda_hip_last_error",
     "msda_hip_forward_f32", "msda_hip_forward_f64", "msda_hip_backward_f32", "msda_hip_backward_f64",

@@ -298,7 +298,9 @@ int dynmask_hip_backward_f32(const float* mask_feats, const float* inst_xy, cons
   if (channels != dynmask::kCf) return dynmask_set_error(DYNMASK_ERR_UNSUPPORTED, "dynmask backward: only 8 mask-feature channels");
   if (batch > dynmask::kMaxBatch) return dynmask_set_error(DYNMASK_ERR_UNSUPPORTED, "dynmask backward: more than DYNMASK_HIP_BWD_MAX_BATCH images");
   if (batch == 0) return 0;
-  if (!num_insts || !grad_feats) return dynmask_set_error(DYNMASK_ERR_NULL_POINTER, "dynmask backward: null pointer argument");
+  // grad_feats == NULL / grad_params == NULL (with grad_xy == NULL): that family of kernels is skipped (round 6, ADVICE r05:
+  // frozen mask features or detached parameters need not pay for the other half)
+  if (!num_insts || (grad_xy && !grad_params)) return dynmask_set_error(DYNMASK_ERR_NULL_POINTER, "dynmask backward: null pointer argument");
   const int HW = H * W;
   int n_all = 0;
   for (int b = 0; b < batch; ++b) {
@@ -306,12 +308,12 @@ int dynmask_hip_backward_f32(const float* mask_feats, const float* inst_xy, cons
     n_all += num_insts[b];
   }
   hipStream_t st = (hipStream_t)stream;
-  if (n_all > 0 && (!mask_feats || !inst_xy || !params || !grad_logits || !grad_params || !workspace))
+  if (n_all > 0 && (!mask_feats || !inst_xy || !params || !grad_logits || (grad_params && !workspace)))
     return dynmask_set_error(DYNMASK_ERR_NULL_POINTER, "dynmask backward: null pointer argument");
-  if (n_all > 0 && workspace_bytes < dynmask_hip_backward_workspace_bytes(n_all, H, W))
+  if (n_all > 0 && grad_params && workspace_bytes < dynmask_hip_backward_workspace_bytes(n_all, H, W))
     return dynmask_set_error(DYNMASK_ERR_BAD_DIMS, "dynmask backward: workspace too small (dynmask_hip_backward_workspace_bytes)");
   // ---- grad_feats: every pixel of every image is written (zeros for an image without instances) -----------------------------
-  {
+  if (grad_feats) {
     const unsigned chunks = (unsigned)((HW + dynmask::kFT - 1) / dynmask::kFT);
     int first = 0;
     for (int b = 0; b < batch; ++b) {
@@ -331,7 +333,7 @@ int dynmask_hip_backward_f32(const float* mask_feats, const float* inst_xy, cons
       first += n;
     }
   }
-  if (n_all > 0) {
+  if (n_all > 0 && grad_params) {
     // ---- grad_params / grad_xy: slices of the pixels per instance, then the slices added in order -----------------------------
     const int parts = dynmask_hip_backward_parts(n_all, H, W);
     float* partial = static_cast<float*>(workspace);

@@ -14,7 +14,7 @@ import threading
 import torch
 
 from . import _lib
-from ._cache import CheckedOnce
+from ._cache import CheckedOnce, tensor_version
 
 _SUFFIX = {torch.float32: "f32", torch.float64: "f64"}
 # CPU tensors: the reference raises "Not implemented on the CPU" (ops/src/ms_deform_attn.h:35-38).  This library has
@@ -24,12 +24,13 @@ _SUFFIX = {torch.float32: "f32", torch.float64: "f64"}
 # reference's error.  GPU tensors never take this route: they go to the HIP kernels or fail loudly.
 STRICT_DEVICE = os.environ.get("MSDA_HIP_STRICT_DEVICE", "0") == "1"
 HOST_THREADS = int(os.environ.get("MSDA_HOST_THREADS", "0"))   # 0: all hardware threads
-# Backward workspace (include/msda_hip.h: msda_hip_backward_workspace_bytes / msda_hip_backward_ws_f32): "1" lends the
-# library a buffer from PyTorch's caching allocator for every fp32 backward call that may need one (stream-ordered, no
-# hipMalloc / device synchronisation inside the library, capturable) at the price of holding ~0.7 GB per encoder-shaped call
-# in the allocator's cache; "0" (default) leaves the library its own per-device workspace, allocated only when
-# msda_bwd_regions is actually chosen.
-TORCH_WORKSPACE = os.environ.get("MSDA_HIP_TORCH_WORKSPACE", "0") == "1"
+# Backward workspace (include/msda_hip.h: msda_hip_backward_workspace_bytes / msda_hip_backward_ws_f32): "1" (the default since
+# round 6) lends the library a buffer from PyTorch's caching allocator for every fp32 backward call that may need one -- stream-
+# ordered, no hipMalloc / device synchronisation inside the library, capturable, and visible to torch.cuda.memory_stats(); the
+# block (~0.7 GB at the R50 training shapes) is cached by the allocator and handed out again call after call.  "0" leaves the
+# library its own per-device workspace behind the allocator's back, allocated (hipMalloc, grown with a device sync, never freed)
+# only when msda_bwd_regions is actually chosen: eight ranks of a node each did that.
+TORCH_WORKSPACE = os.environ.get("MSDA_HIP_TORCH_WORKSPACE", "1") != "0"
 
 
 # ---- call context of the automatic forward-kernel choice (include/msda_hip.h: msda_hip_set_call_context) ----------------
@@ -78,8 +79,8 @@ def reenter(site):
 # thread with the forward's saved tensors: it is matched to its forward by the storage of `sampling_loc` (a tensor the
 # layer made for this call alone and autograd keeps alive until then).  A caller that repeats ONE call in a loop on the same
 # shapes object walks through the 16 derived slots (each settles on its kernel at its third visit): wrap such loops in
-# call_site().  This repository's own modules pass explicit sites 1..63 from a counter of instances; a
-# process that mixes both kinds of module may see two layers share a slot's history, which costs speed, never results.
+# call_site().  This repository's own modules pass explicit sites 1..47 from a counter of instances (the derived range 48..63
+# is reserved: round 6); unmatched_backward_calls() counts the backward calls that found no forward.
 AUTO_SITE_BASE, AUTO_SITES = 48, 16
 _AUTO_BWD_KEEP = 256                      # forward calls remembered for their backward (inference never consumes them)
 
@@ -92,14 +93,18 @@ class _AutoSites:
         self.ordinal = 0
         self.by_loc = {}                  # sampling_loc.data_ptr() -> site, insertion-ordered
         self.last = -1                    # the site the last context carried (tests, bench)
+        self.unmatched = 0                # backward calls whose forward was not found (they take the history-free kernel)
 
     def forward(self, spatial_shapes, sampling_loc):
         import weakref
         with self.lock:
             cur = self.shapes_ref() if self.shapes_ref is not None else None
-            if cur is not spatial_shapes or self.shapes_version != spatial_shapes._version:
+            # (tensor_version: -1 for inference tensors -- a shapes tensor built under torch.inference_mode(), as Deformable-DETR
+            # does, has no version counter and `_version` raises on it)
+            version = tensor_version(spatial_shapes)
+            if cur is not spatial_shapes or self.shapes_version != version:
                 self.shapes_ref = weakref.ref(spatial_shapes)
-                self.shapes_version = spatial_shapes._version
+                self.shapes_version = version
                 self.ordinal = 0
             site = AUTO_SITE_BASE + self.ordinal % AUTO_SITES
             self.ordinal += 1
@@ -111,7 +116,10 @@ class _AutoSites:
 
     def backward(self, sampling_loc):
         with self.lock:
-            return self.by_loc.pop(int(sampling_loc.data_ptr()), None)
+            site = self.by_loc.pop(int(sampling_loc.data_ptr()), None)
+            if site is None:
+                self.unmatched += 1
+            return site
 
 
 _auto = _AutoSites()
@@ -138,6 +146,13 @@ def _auto_site(spatial_shapes, sampling_loc, backward=False):
         site = _auto.backward(sampling_loc)
         return -1 if site is None else site
     return _auto.forward(spatial_shapes, sampling_loc)
+
+
+def unmatched_backward_calls():
+    """How many encoder-shaped backward calls made outside call_site() blocks could not be matched to their forward (a cast or
+    contiguous copy of sampling_loc, activation checkpointing, a forward older than the last 256): those calls are correct
+    but take the history-free backward kernel.  A count that grows with the steps says the integration should pass sites."""
+    return _auto.unmatched
 
 
 def last_call_site():
@@ -456,9 +471,11 @@ def aligned_bilinear_forward(x, factor):
     return out
 
 
-def dynmask_backward(mask_feats, inst_xy, params, num_insts, stride, rel_coord, grad_logits, need_xy=True):
+def dynmask_backward(mask_feats, inst_xy, params, num_insts, stride, rel_coord, grad_logits, need_xy=True, need_feats=True,
+                     need_params=True):
     """Backward of dynmask_forward (include/dynmask_hip.h: dynmask_hip_backward_f32): grad_logits [n_inst, H, W] ->
-    (grad_mask_feats [N, 8, H, W], grad_params [n_inst, P], grad_inst_xy [n_inst, 2] or None).  Deterministic (no float
+    (grad_mask_feats [N, 8, H, W], grad_params [n_inst, P], grad_inst_xy [n_inst, 2] or None).  need_feats / need_params /
+    need_xy = False: that gradient is None and its kernels are not launched (round 6).  Deterministic (no float
     atomics); the activations are recomputed, the workspace (partial sums of the pixel slices) comes from PyTorch's
     caching allocator for the duration of the call."""
     lib = _lib.load()
@@ -475,20 +492,21 @@ def dynmask_backward(mask_feats, inst_xy, params, num_insts, stride, rel_coord, 
         raise RuntimeError("dynmask_backward: inconsistent shapes")
     if N > _lib.DYNMASK_BWD_MAX_BATCH:
         raise RuntimeError("dynmask_backward: at most %d images per call" % _lib.DYNMASK_BWD_MAX_BATCH)
-    g_feats = torch.empty_like(mask_feats)
-    g_params = torch.empty_like(params)
+    g_feats = torch.empty_like(mask_feats) if need_feats else None
+    g_params = torch.empty_like(params) if (need_params or need_xy) else None     # (the reference points' gradient comes out of the same pass)
     g_xy = torch.empty_like(inst_xy) if need_xy else None
-    ws_bytes = int(lib.dynmask_hip_backward_workspace_bytes(n_all, H, W))
+    ws_bytes = int(lib.dynmask_hip_backward_workspace_bytes(n_all, H, W)) if g_params is not None else 0
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
     arr = (ctypes.c_int * max(N, 1))(*counts)
     with torch.cuda.device(dev):
         rc = lib.dynmask_hip_backward_f32(mask_feats.data_ptr(), inst_xy.data_ptr(), params.data_ptr(), arr, N, C, H, W, int(stride),
-                                          int(bool(rel_coord)), grad_logits.data_ptr(), g_feats.data_ptr(), g_params.data_ptr(),
+                                          int(bool(rel_coord)), grad_logits.data_ptr(), g_feats.data_ptr() if g_feats is not None else None,
+                                          g_params.data_ptr() if g_params is not None else None,
                                           g_xy.data_ptr() if g_xy is not None else None, ws.data_ptr(), ws_bytes,
                                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     if rc != 0:
         _raise(rc)
-    return g_feats, g_params, g_xy
+    return g_feats, (g_params if need_params else None), g_xy
 
 
 def aligned_bilinear_backward(grad_out, factor):

@@ -116,9 +116,9 @@ class DynMaskFunction(torch.autograd.Function):
     def backward(ctx, grad_logits):
         mask_feats, inst_xy, params = ctx.saved_tensors
         g_feats, g_params, g_xy = _ext.dynmask_backward(mask_feats, inst_xy, params, ctx.counts, ctx.stride, ctx.rel_coord,
-                                                        grad_logits.contiguous(), need_xy=ctx.needs_input_grad[1])
-        return (g_feats if ctx.needs_input_grad[0] else None, g_xy if ctx.needs_input_grad[1] else None,
-                g_params if ctx.needs_input_grad[2] else None, None, None, None)
+                                                        grad_logits.contiguous(), need_xy=ctx.needs_input_grad[1],
+                                                        need_feats=ctx.needs_input_grad[0], need_params=ctx.needs_input_grad[2])
+        return (g_feats, g_xy, g_params, None, None, None)
 
 
 def dynamic_mask_logits(mask_feats, reference_points, mask_head_params, num_insts, mask_feat_stride, rel_coord=True):

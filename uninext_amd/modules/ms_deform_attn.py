@@ -43,7 +43,9 @@ class MSDeformAttn(CachedModuleMixin, nn.Module):
     fuse_prologue = os.environ.get("UNINEXT_AMD_NO_FUSED", "0") != "1"
     # training: MSDeformAttnFusedFunction (fused forward from the raw Linear outputs; backward recomputes the locations / weights
     # and runs the operator's backward kernels) instead of the PyTorch prologue + MSDeformAttnFunction
-    fuse_training_prologue = True          # (class attribute; UNINEXT_AMD_NO_FUSED=1 switches both fusions off)
+    # (class attribute; UNINEXT_AMD_NO_FUSED=1 switches both fusions off, UNINEXT_AMD_NO_FUSED_TRAINING=1 this one alone -- the
+    # switch of rounds 3-4 that round 5 had dropped without notice: ADVICE r05)
+    fuse_training_prologue = os.environ.get("UNINEXT_AMD_NO_FUSED_TRAINING", "0") != "1"
     fast_linear = os.environ.get("UNINEXT_AMD_SPLIT_BF16", "0") == "1"   # opt-in: split-bf16 projections at inference
 
     def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4):
@@ -82,14 +84,15 @@ class MSDeformAttn(CachedModuleMixin, nn.Module):
 
     # -- argument check of :93 without a device->host sync per call -----------------------------------------
     _shape_checks = CheckedOnce()
-    _instances = 0          # every instance is a call site of its own for the library's forward-kernel choice (sites 1..63)
+    _instances = 0          # every instance is a call site of its own for the library's forward-kernel choice (sites 1..47;
+                            # 48..63 belong to the sites ext.py derives for callers that pass none)
 
     def _site(self):
         site = self.__dict__.get("_msda_site")
         if site is None:
             cls = MSDeformAttn
             cls._instances += 1
-            site = self.__dict__["_msda_site"] = 1 + (cls._instances - 1) % 63
+            site = self.__dict__["_msda_site"] = 1 + (cls._instances - 1) % 47
         return site
 
     @classmethod
