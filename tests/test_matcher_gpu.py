@@ -23,6 +23,58 @@ def test_hungarian_on_device_matches_reference(name, fused):
         assert np.array_equal(i.numpy(), g[f"hung_i_{b}"]) and np.array_equal(j.numpy(), g[f"hung_j_{b}"])
 
 
+def test_default_hungarian_cost_is_bitwise_the_reference_composition():
+    """the contract of this row is bit-exact indices.  The DEFAULT cost matrix is the reference's own chain of
+    PyTorch operations on the device (matcher.py:476-498) -- bitwise equal to it on every fixture and on 200 seeded batches with
+    multi-token targets -- and on constructed near-ties (two queries whose costs for one target differ by one unit in the last
+    place, and exact ties) the device assignment returns SciPy's indices on that very matrix."""
+    from scipy.optimize import linear_sum_assignment
+    from uninext_amd.matcher import box_cxcywh_to_xyxy, focal_token_cost, generalized_box_iou
+    assert HungarianMatcherVL.fused_cost is False
+    matcher = HungarianMatcherVL(cost_class=2, cost_bbox=5, cost_giou=2)
+
+    def composition(logits, boxes, tgt_map, tgt_boxes):
+        cls = focal_token_cost(logits.sigmoid(), tgt_map)
+        l1 = torch.cdist(boxes, tgt_boxes, p=1)
+        gi = -generalized_box_iou(box_cxcywh_to_xyxy(boxes), box_cxcywh_to_xyxy(tgt_boxes))
+        return 5 * l1 + 2 * cls + 2 * gi
+
+    cases = []
+    for name in matcher_names():
+        g, bs, outputs, targets = _case(name, device="cuda:0")
+        if sum(len(t["boxes"]) for t in targets):
+            cases.append((outputs, targets))
+    gen = torch.Generator().manual_seed(77)
+    for k in range(200):
+        Q, T, G = 60 + k % 7, 32, 3 + k % 5
+        pm = torch.zeros(G, T, dtype=torch.bool)
+        for t in range(G):
+            n_tok = 1 + int(torch.randint(0, 9, (1,), generator=gen))          # 1..9 tokens: PyTorch's mean(-1) in every regime
+            pm[t, torch.randperm(T, generator=gen)[:n_tok]] = True
+        cxcy = torch.rand(G, 2, generator=gen) * 0.6 + 0.2
+        tb = torch.cat([cxcy, torch.rand(G, 2, generator=gen) * 0.2 + 0.05], 1)
+        outputs = {"pred_logits": torch.randn(1, Q, T, generator=gen).cuda(),
+                   "pred_boxes": torch.cat([torch.rand(1, Q, 2, generator=gen) * 0.6 + 0.2, torch.rand(1, Q, 2, generator=gen) * 0.2 + 0.05], 2).cuda()}
+        cases.append((outputs, [{"boxes": tb.cuda(), "positive_map": pm.cuda()}]))
+    for outputs, targets in cases:
+        logits, boxes = outputs["pred_logits"].flatten(0, 1), outputs["pred_boxes"].flatten(0, 1)
+        tgt_map = torch.cat([t["positive_map"] for t in targets])
+        tgt_boxes = torch.cat([t["boxes"] for t in targets])
+        assert torch.equal(matcher.cost_matrix(logits, boxes, tgt_map, tgt_boxes), composition(logits, boxes, tgt_map, tgt_boxes))
+    # near-ties: duplicate a query, then move its copy's cost for one target by exactly one ulp either way (and not at all)
+    outputs, targets = cases[-1]
+    for shift in (-1, 0, 1):
+        logits, boxes = outputs["pred_logits"][0].clone(), outputs["pred_boxes"][0].clone()
+        logits[1], boxes[1] = logits[0], boxes[0]
+        cost = composition(logits, boxes, targets[0]["positive_map"], targets[0]["boxes"])
+        bits = cost.view(torch.int32)
+        bits[1, 0] += shift * (1 if float(cost[1, 0]) >= 0 else -1)
+        from uninext_amd import ext
+        (i, j), = ext.lsap_batch([cost], check=True)
+        ri, rj = linear_sum_assignment(cost.cpu().numpy())
+        assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(j.cpu().numpy(), rj), shift
+
+
 OTA_NAMES = [n for n in matcher_names() if "encoder" not in n]
 
 

@@ -30,10 +30,13 @@ selected-query counts are copied back, once per call, to cut the index tensors t
 (tests/test_matcher_gpu.py asserts that with torch.cuda.set_sync_debug_mode).  CPU inputs and `device_ota = False` run
 the PyTorch composition below -- the reference's data flow with its per-target loops.
 
-`fused_cost` (Hungarian cost matrix in one kernel) evaluates the composition's float32 operations in its order, but its
-logf is this ROCm's device library's, which differs from the one PyTorch was built with by one unit in the last place on a
-third of the arguments: the class term agrees with the composition to 5e-7, not bitwise (tests/test_matcher_gpu.py); the
-assignment of every reference-minted fixture is unchanged.  Set `fused_cost = False` for the composition itself.
+`fused_cost` (Hungarian cost matrix in one kernel; OPT-IN since round 6) evaluates the composition's float32 operations in its
+order, but its logf is this ROCm's device library's, which differs from the one PyTorch was built with by one unit in the last
+place on a third of the arguments, and PyTorch's `mean(-1)` over five or more tokens adds in another order: the class term agrees
+with the composition to 5e-7, not bitwise (tests/test_matcher_gpu.py).  The assignment of every reference-minted fixture is
+unchanged, but a near-tie between two queries inside that margin could flip silently -- so the DEFAULT cost matrix is the
+reference's own PyTorch composition on the device (bitwise the reference's by construction), and only the
+assignment itself (SciPy's algorithm with SciPy's tie rules, include/lsap_hip.h) is this library's.
 """
 import torch
 from scipy.optimize import linear_sum_assignment
@@ -109,7 +112,8 @@ class HungarianMatcherVL(nn.Module):
 
     batched_topk = True   # dynamic-k selection without a host sync per ground-truth box (same indices; see the tests)
     device_lsap = True    # GPU inputs: solve the assignment on the device (include/lsap_hip.h) instead of C.cpu() + SciPy
-    fused_cost = True     # GPU fp32 inputs: the cost matrix in one kernel (include/matcher_cost_hip.h) instead of ~40 launches
+    fused_cost = False    # opt-in (GPU fp32 inputs): the cost matrix in one kernel (include/matcher_cost_hip.h) instead of ~40 launches;
+                          # its class term is 1 ulp of logf from the composition's -- the default is the bit-exact composition
     device_ota = True     # GPU fp32 inputs: simOTA of the whole batch in two kernels (include/ota_hip.h), one host sync per call
 
     def __init__(self, cost_class: float = 1, cost_bbox: float = 1, cost_giou: float = 1, cost_mask: float = 1):
@@ -118,8 +122,9 @@ class HungarianMatcherVL(nn.Module):
         assert cost_class != 0 or cost_bbox != 0 or cost_giou != 0 or cost_mask != 0, "all costs cant be 0"
 
     def cost_matrix(self, logits, boxes, tgt_map, tgt_boxes):
-        """[num_pred, num_gt] cost of matcher.py:476-498.  GPU fp32: one kernel with the composition's float32 operation
-        order (`fused_cost`; class term to 1 ulp of logf, see the module docstring); otherwise the composition itself."""
+        """[num_pred, num_gt] cost of matcher.py:476-498: the reference's composition (default: bitwise the reference's on the same
+        device); with `fused_cost = True` on GPU fp32 inputs one kernel with the composition's float32 operation order (class
+        term to 1 ulp of logf, see the module docstring)."""
         if (self.fused_cost and logits.is_cuda and logits.dtype == torch.float32 and boxes.dtype == torch.float32
                 and tgt_boxes.dtype == torch.float32 and tgt_boxes.shape[0] > 0 and tgt_map.dtype in (torch.bool, torch.uint8)):
             from . import ext as _ext
