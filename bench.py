@@ -671,6 +671,9 @@ def measure_model_slice(reps=6):
     return out
 
 
+CPU_WARMUPS = 3
+
+
 def cpu_baseline(flavour):
     """Bounded sample of the same workload on the host: one encoder call and one decoder call of the
     reference's grid_sample path (N = 2); a step is 6 of each.  grid_sample's OpenMP scaling collapses when
@@ -702,12 +705,13 @@ def cpu_baseline(flavour):
     runs = 10 if probe[threads] < 2.0 else 5
     per_step, med = 0.0, {}
     for kind, layers in (("encoder", ENC_LAYERS), ("decoder", DEC_LAYERS)):
-        run(kind)
+        for _ in range(CPU_WARMUPS):                          # 3 warm-ups, then >= 10 timed runs, median
+            run(kind)
         ts = sorted(run(kind) for _ in range(runs))
         med[kind] = 0.5 * (ts[(runs - 1) // 2] + ts[runs // 2])
         per_step += layers * med[kind]
     return {"value": BATCH / per_step, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": "median of %d timed runs (after 1 warm-up) of ONE encoder call (%.3f s) and ONE decoder call "
+            "sample": "median of %d timed runs (after 3 warm-ups) of ONE encoder call (%.3f s) and ONE decoder call "
                       "(%.4f s) at N=2, x6 each per step; oracle/msda_gridsample.py (= ms_deform_attn_core_pytorch), "
                       "fp32, torch.set_num_threads(%d) of %d logical cores (fastest of the probed counts %s)"
                       % (runs, med["encoder"], med["decoder"], threads, ncpu, sorted(probe))}

@@ -1,4 +1,4 @@
-"""CPU, world_size 2 over gloo: the multi-rank plumbing bench.py uses (per-rank shards, barrier,
+"""CPU, world_size 2 and 8 over gloo: the multi-rank plumbing bench.py uses (per-rank shards, barrier,
 max-over-ranks timing).  The data path itself has no collective."""
 import os
 import sys
@@ -141,19 +141,20 @@ def _main_worker(rank, world, port, fail_rank, fail_where, out):
     out.put((rank, json.loads(line) if line else None, dist.is_initialized()))
 
 
-def _run_main(fail_rank, fail_where):
+def _run_main(fail_rank, fail_where, world=2):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + (os.getpid() % 2000) + {"none": 0, "train_setup": 1, "train_timed": 2, "train_inputs": 3}[fail_where]
-    procs = [ctx.Process(target=_main_worker, args=(r, 2, port, fail_rank, fail_where, q)) for r in range(2)]
+    port = 31500 + (os.getpid() % 2000) + {"none": 0, "train_setup": 1, "train_timed": 2, "train_inputs": 3}[fail_where] + 10 * world
+    procs = [ctx.Process(target=_main_worker, args=(r, world, port, fail_rank, fail_where, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict((r, (line, alive)) for r, line, alive in (q.get(timeout=180) for _ in procs))
+    res = dict((r, (line, alive)) for r, line, alive in (q.get(timeout=300) for _ in procs))
     for p in procs:
         p.join(60)
         assert p.exitcode == 0           # nobody hung, nobody died
-    assert res[1][0] is None             # rank 0 prints the line, alone
-    assert not res[0][1] and not res[1][1]      # the process group was destroyed on both ranks (behind the last exchange)
+    for r in range(1, world):
+        assert res[r][0] is None         # rank 0 prints the line, alone
+    assert not any(res[r][1] for r in range(world))      # the process group was destroyed on every rank (behind the last exchange)
     return res[0][0]
 
 
@@ -180,3 +181,18 @@ def test_main_survives_a_leg_that_fails_on_one_rank(where):
         # of the step surfaces inside ddp's own set-up phase or timed phase -- either way nobody hangs
         assert "ddp" in line
     assert line["matcher"]["ran_on"] == 0
+
+
+def test_main_eight_ranks_all_legs_and_a_failure_on_the_last_rank():
+    """the first real 8-GPU run must not be the first time rank 7 executes.  bench.main() over EIGHT gloo ranks
+    (one node's worth), every leg incl. `train_step` and the bucketed `ddp` all-reduce, rank-dependent seeds, derived sites; then
+    again with rank 7 raising inside the timed train steps -- every rank abandons the leg at the next exchange, the line is
+    printed, nobody hangs."""
+    line = _run_main(-1, "none", world=8)
+    assert line["n_gpus"] == 8 and line["rccl_ranks"] == 8 and line["scaling"] == "weak"
+    assert line["train_step"]["ms_per_step"] > 0
+    assert line["ddp"]["rccl_ranks"] == 8 and line["busbw"] == line["ddp"]["busbw_GBs"] > 0
+    assert line["matcher"]["ran_on"] == 0
+    line = _run_main(7, "train_timed", world=8)
+    assert line["value"] > 0 and line["n_gpus"] == 8
+    assert "another rank failed" in line["train_step"]["error"] and "ddp" in line
