@@ -825,6 +825,9 @@ def main(argv=None):
                 "workload": "BASELINE configs[1]: R50 COCO det+seg inference bs=2 800x1333 -- hot path only: "
                             "6 encoder (Lq=S=22223) + 6 decoder (Lq=900) MSDeformAttn forward calls per step, "
                             "M=8 D=32 L=4 P=4, '%s' sampling locations" % args.flavour,
+                "scope": "`value` counts frames whose TWELVE MSDeformAttn launches ran -- the model around them (backbone, projections, "
+                         "FFN, heads: PyTorch-ROCm) is not in the timed region; `model_slice` is the widest thing timed and "
+                         "`model_slice.msda_share_of_slice` says what part of it these launches are",
                 "frames_per_step_per_gpu": BATCH,
                 "parallelism": "dp%d (independent replicas, no collective in the timed region)" % world,
                 "kernel": enc_kernel,

@@ -438,6 +438,72 @@ def test_tiled_backward_fixed_point_bound_under_high_dynamic_range(kernel, dev, 
     assert float(err_f.max()) < 1e-5 * gmax
 
 
+@pytest.mark.parametrize("kernel", ["msda_bwd_tiled", "msda_bwd_win"])
+def test_fixed_point_grad_value_under_the_gradient_of_a_detection_loss(kernel, dev, api):
+    """the fixed-point kernels round to 2^-22 of the TILE's largest upstream gradient -- shown so far on N(0, 1) gradients
+    and one synthetic 8-decade case.  Here grad_output is what a detection loss sends back: the operator's output goes through an
+    output projection and a classification head (sigmoid focal loss, ~20 positive locations per image among 22 k, as the encoder's
+    proposal loss of dd/deformable_detr.py has it) plus an L1 box head on the positives -- a heavy-tailed field: a few queries carry
+    gradients 1e3..1e5 times the median's.  Against the float64 oracle: the error relative to the largest gradient, the relative
+    error summed over all elements, the cosine of the two grad_value fields, and what training consumes -- the gradient of the value
+    projection's weight, sum_pixels input^T grad_value -- against the same quantity from the float-atomic kernel."""
+    from oracle import msda_oracle
+    from uninext_amd import workloads
+    MSDA, lib = api
+    levels = ((48, 64), (24, 32), (12, 16), (6, 8))
+    x = _inputs("model", levels, 91, dev)
+    S = x["value"].shape[1]
+    g = torch.Generator().manual_seed(92)
+    out = MSDA.ms_deform_attn_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], 64).detach().requires_grad_(True)
+    w_out = (torch.randn(256, 256, generator=g) / 16).to(dev)
+    w_cls = (torch.randn(256, 80, generator=g) / 16).to(dev)
+    w_box = (torch.randn(256, 4, generator=g) / 16).to(dev)
+    h = torch.relu(out @ w_out)
+    logits = h @ w_cls - 4.6                                              # prior probability 0.01, as the reference initialises its heads
+    target = torch.zeros(2, S, 80, device=dev)
+    pos = torch.randint(0, S, (2, 20), generator=g).to(dev)
+    cls = torch.randint(0, 80, (2, 20), generator=g).to(dev)
+    target[torch.arange(2, device=dev)[:, None], pos, cls] = 1.0
+    p = logits.sigmoid()
+    ce = torch.nn.functional.binary_cross_entropy_with_logits(logits, target, reduction="none")
+    focal = (0.25 * target + 0.75 * (1 - target)) * ce * ((1 - (p * target + (1 - p) * (1 - target))) ** 2)
+    boxes = (h @ w_box).sigmoid()
+    l1 = (boxes[torch.arange(2, device=dev)[:, None], pos] - torch.rand(2, 20, 4, generator=g).to(dev)).abs().sum()
+    loss = focal.sum() / 40.0 + 5.0 * l1 / 40.0
+    go, = torch.autograd.grad(loss, out)
+    go = go.contiguous()
+    per_query = go.abs().amax(-1).flatten()
+    med, top = float(per_query.median()), float(per_query.max())
+    print("grad_output per query: median %.2e, max %.2e (x %.0f)" % (med, top, top / med))
+    assert top > 300 * med                                                  # heavy-tailed, as intended
+    tgv, _, _ = msda_oracle.backward(go.double(), x["value"].double(), x["shapes"], x["lsi"], x["loc"].double(), x["attn"].double())
+    gv, _, _ = _bwd(MSDA, lib, x, go, kernel)
+    assert lib.last_kernel("backward") == kernel
+    gv_f, _, _ = _bwd(MSDA, lib, x, go, "msda_bwd_generic")
+    a, f = gv.cpu().numpy().astype(np.float64), gv_f.cpu().numpy().astype(np.float64)
+    t = np.asarray(tgv, dtype=np.float64).reshape(a.shape)
+    gmax = np.abs(t).max()
+    step = float(go.abs().max()) * 2.0 ** -22                                # the largest rounding step of any tile (include/msda_hip.h)
+    rel_max = np.abs(a - t).max() / gmax
+    rel_max_f = np.abs(f - t).max() / gmax
+    rel_sum = np.abs(a - t).sum() / np.abs(t).sum()
+    cos = float((a * t).sum() / np.sqrt((a * a).sum() * (t * t).sum()))
+    # what training consumes: grad of the value projection's weight = input^T grad_value (input: any fixed activations)
+    inp = torch.randn(2 * S, 256, generator=g).numpy().astype(np.float64)
+    gw_t = inp.T @ t.reshape(2 * S, 256)
+    gw_a, gw_f = inp.T @ a.reshape(2 * S, 256), inp.T @ f.reshape(2 * S, 256)
+    e_a, e_f = np.abs(gw_a - gw_t).max() / np.abs(gw_t).max(), np.abs(gw_f - gw_t).max() / np.abs(gw_t).max()
+    print("%s: max |err| = %.1f steps of 2^-22 max|grad_output| = %.2e of max |grad_value| (float atomics: %.2e), sum |err| / sum |grad_value| "
+          "%.2e, 1 - cos %.1e; value-projection weight gradient: max rel err %.2e (float atomics: %.2e)" % (
+              kernel, np.abs(a - t).max() / step, rel_max, rel_max_f, rel_sum, 1.0 - cos, e_a, e_f))
+    # Measured (MI355X, round 6): 52 steps = 4.6e-5 of max |grad_value| (float atomics 1.7e-6), sum |err| / sum |grad_value| 2.5e-4,
+    # 1 - cos 5e-9, weight gradient 9.3e-5 (float atomics 8.9e-7).  The fixed point IS ~50-100x coarser than float atomics on such a
+    # field -- inside 1e-4 of what training consumes, and stated in include/msda_hip.h / INTEGRATION.md with these numbers; callers that
+    # need the reference's per-element rounding pin msda_bwd_generic (float atomics) or msda_bwd_regions (float64 sums).
+    assert np.abs(a - t).max() < 64.0 * step and rel_sum < 1e-3 and 1.0 - cos < 1e-8
+    assert e_a < 2e-4 and e_f < 1e-5
+
+
 @pytest.mark.parametrize("kernel,kind", [("msda_bwd_tiled", "encoder"), ("msda_bwd_win", "encoder"), ("msda_bwd_dec", "decoder")])
 def test_fixed_point_backward_with_huge_upstream_gradients(kernel, kind, dev, api):
     """the scale exponent of the int32 LDS accumulators is clamped to [-90, 90]; a bound >= 2^121 (grad_output
