@@ -84,6 +84,10 @@ def test_full_size_r50_head(dev):
         out = head(x, None)                                          # HIP route: split-bf16 from packed weights
         head.exact_fp32 = True
         out_exact = head(x, None)                                    # the default: fp32 through MIOpen
+        head.own_exact_conv = True
+        out_own = head(x, None)                                      # exact fp32 through conv3x3_hip_packed_exact_f32 (round 6: opt-in)
+        assert torch.equal(head(x, None), out_own)                   # one fixed summation order: bitwise repeatable
+        head.own_exact_conv = False
         F = torch.nn.functional
         f = F.relu(head.lay3(x[-1]))
         f = F.relu(head.lay4(x[-2] + F.interpolate(f, size=x[-2].shape[-2:], mode="nearest")))
@@ -92,6 +96,7 @@ def test_full_size_r50_head(dev):
     assert out.shape == (2, 8, 100, 167)
     assert float((out - want).abs().max()) < 1e-4 * max(1.0, float(want.abs().max()))
     assert float((out_exact - want).abs().max()) < 1e-5 * max(1.0, float(want.abs().max()))
+    assert float((out_own - want).abs().max()) < 1e-5 * max(1.0, float(want.abs().max()))
     # oracle on the top-left 12 x 14 crop of jia_dcn's output (needs a 13 x 15 input crop; zero padding on two sides)
     with torch.no_grad():
         xin = torch.randn(2, 256, 100, 167, device=dev)

@@ -594,8 +594,12 @@ constexpr int CONV3X3_EXACT_PITCH = 20;
         if (t + 2 < 9) load_x(buf, t + 2, x0);
         tap_mfma(x1, wc[t + 1]);
       }
+      // Round 6: the next chunk's halo goes into the other buffer in the MIDDLE of the chunk, not in front of its barrier (that
+      // buffer's last readers left before the previous barrier; the loads were issued at the chunk's start): the barrier no longer
+      // waits for the slowest wave's global loads and LDS writes -- 418 -> 376 us on the 256 -> 256 layer at 100 x 167, 803 -> 743 us
+      // for the mask head's module forward (profiles/r06_conv3x3_exact.txt; after tap 2 or tap 6 instead: slower)
+      if (t == 4 && chunk + 1 < nchunks) store_halo(buf ^ 1);
     }
-    if (chunk + 1 < nchunks) store_halo(buf ^ 1);
     __syncthreads();
     load_x(buf ^ 1, 0, x0);                            // (after the last chunk: stale data, never used)
 #pragma unroll

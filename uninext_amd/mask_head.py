@@ -169,21 +169,29 @@ def _packed_weight(conv):
     return packed_weight(conv, _ext.conv3x3_pack_weight)
 
 
-def conv3x3_relu(x, conv, exact=True):
+def _hip_conv_ok(x, conv):
+    needs_grad = torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad)
+    return (not needs_grad and tuple(conv.kernel_size) == (3, 3) and tuple(conv.padding) == (1, 1)
+            and tuple(conv.stride) == (1, 1) and tuple(conv.dilation) == (1, 1) and conv.groups == 1
+            and _ext.conv3x3_supported(x, conv.weight))
+
+
+def conv3x3_relu(x, conv, exact=True, own_exact=False):
     """`F.relu(conv(x))` for a 3x3 / padding 1 nn.Conv2d.
-    exact=True (default): fp32 arithmetic as in the reference, through the PyTorch-ROCm / MIOpen convolution (~750 us for the
-    head's module forward at bs 2).  This library's own exact-fp32 MFMA convolution (conv3x3_hip_packed_exact_f32,
-    include/conv3x3_hip.h) was WITHDRAWN from the module in round 5: it loses to MIOpen on four of the head's five layers
-    (929-939 us for the module, profiles/r04_conv3x3_exact.txt) -- it stays in the C ABI as a tested entry point.
+    exact=True (default): fp32 arithmetic as in the reference, through the PyTorch-ROCm / MIOpen convolution (~740 us for the
+    head's module forward at bs 2).  own_exact=True: the same through this library's own exact-fp32 MFMA convolution
+    (conv3x3_hip_packed_exact_f32, include/conv3x3_hip.h; cached packed weights; inference only) -- round 6: 744 us for the module
+    against MIOpen's 738 on one box (faster on lay3 / lay4 / lay1, 3 % behind on the 256 -> 256 layer at 100 x 167:
+    profiles/r06_conv3x3_exact.txt), a tie that does not justify changing the default; round 5 had withdrawn it at 929-939 us.
     exact=False opts into the split-bf16 MFMA kernels of include/conv3x3_hip.h from cached packed weights (~390 us, ~2e-5 of
     the output scale, inside the 1e-4 parity bound); layers they do not take (input channels not a multiple of 16) go
     through conv3x3_hip_f32.  Training, CPU, other dtypes or geometries: PyTorch."""
     if exact:
+        if own_exact and conv.weight.shape[1] % 16 == 0 and _hip_conv_ok(x, conv):
+            pe = packed_weight(conv, lambda w: _ext.conv3x3_pack_weight(w, exact=True), slot="_msda_packed_exact")
+            return _ext.conv3x3_packed_forward(x.contiguous(), pe, conv.weight.shape[0], conv.bias, relu=True, exact=True)
         return F.relu(conv(x))
-    needs_grad = torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad)
-    if (not needs_grad and tuple(conv.kernel_size) == (3, 3) and tuple(conv.padding) == (1, 1)
-            and tuple(conv.stride) == (1, 1) and tuple(conv.dilation) == (1, 1) and conv.groups == 1
-            and _ext.conv3x3_supported(x, conv.weight)):
+    if _hip_conv_ok(x, conv):
         if conv.weight.shape[1] % 16 == 0:
             return _ext.conv3x3_packed_forward(x.contiguous(), _packed_weight(conv), conv.weight.shape[0], conv.bias, relu=True)
         return _ext.conv3x3_forward(x.contiguous(), conv.weight.contiguous(), conv.bias, relu=True)
@@ -199,6 +207,8 @@ class MaskHeadSmallConv(CachedModuleMixin, torch.nn.Module):
     # True (default): the reference's fp32 arithmetic (MIOpen convolutions); False -- or env UNINEXT_AMD_SPLIT_BF16=1 -- opts
     # into the split-bf16 MFMA kernels (3 of 4 partial products, ~2e-5 of the output scale; the fast ones)
     exact_fp32 = os.environ.get("UNINEXT_AMD_SPLIT_BF16", "0") != "1"
+    # exact fp32 through this library's own MFMA convolution instead of MIOpen (a tie in round 6, see conv3x3_relu); inference only
+    own_exact_conv = False
 
     def __init__(self, dim, fpn_dims, context_dim, use_raft=False, up_rate=4):
         super().__init__()
@@ -239,9 +249,9 @@ class MaskHeadSmallConv(CachedModuleMixin, torch.nn.Module):
 
     def forward(self, x, fpns):
         f = fpns if fpns is not None else (None, None, None)
-        e = self.exact_fp32
-        fused = conv3x3_relu(self._merge(x[-1], getattr(self, "adapter1", None), f[0], None), self.lay3, e)
-        fused = conv3x3_relu(self._merge(x[-2], getattr(self, "adapter2", None), f[1], fused), self.lay4, e)
-        fused_fpn = conv3x3_relu(self._merge(x[-3], getattr(self, "adapter3", None), f[2], fused), self.jia_dcn, e)
-        fused = conv3x3_relu(fused_fpn, self.lay1, e)
-        return conv3x3_relu(fused, self.lay2, e)
+        e, o = self.exact_fp32, self.own_exact_conv
+        fused = conv3x3_relu(self._merge(x[-1], getattr(self, "adapter1", None), f[0], None), self.lay3, e, o)
+        fused = conv3x3_relu(self._merge(x[-2], getattr(self, "adapter2", None), f[1], fused), self.lay4, e, o)
+        fused_fpn = conv3x3_relu(self._merge(x[-3], getattr(self, "adapter3", None), f[2], fused), self.jia_dcn, e, o)
+        fused = conv3x3_relu(fused_fpn, self.lay1, e, o)
+        return conv3x3_relu(fused, self.lay2, e, o)
