@@ -97,6 +97,10 @@ int msda_hip_forward_f64(const double* value, const int64_t* spatial_shapes,
  * msda_bwd_regions (backward variant 6) has no fixed point: every pixel's corners are added in float64 by the one workgroup
  * that owns the pixel and rounded to float ONCE (each term is the float product weight x attention x grad_output as in the
  * reference); its grad_value differs from the exact sum by one float rounding.
+ * msda_bwd_dst (backward variant 8, round 6; fp32 calls with channels 32 and 4 levels x 4 points, meant for the decoder's shapes)
+ * is its counterpart for few queries on many pixels: float64 sums per 16 x 16 pixel tile in LDS, one rounding per element and
+ * workgroup, the few workgroups of a coarse tile meeting in float atomics; 6-12 % slower than msda_bwd_dec at the R50 shapes and
+ * therefore not variant 0's choice: msda_hip_set_variant(1, 8) selects it where the fixed point above is unwanted.
  */
 int msda_hip_backward_f32(const float* grad_output, const float* value,
                           const int64_t* spatial_shapes, const int64_t* level_start_index,

@@ -68,11 +68,11 @@ def test_abi_version_and_variant_table(lib):
         assert lib.msda_hip_set_variant(0, k) != 0 and "experiment" in _lib.last_error()
     gotb = _lib.variants("backward")
     assert [n.replace("exp:", "") for n in gotb] == ["auto", "msda_bwd_generic", "msda_bwd_lanegroup", "msda_bwd_tiled", "msda_bwd_win",
-                                                     "msda_bwd_dec", "msda_bwd_regions", "msda_bwd_win2"]
+                                                     "msda_bwd_dec", "msda_bwd_regions", "msda_bwd_win2", "msda_bwd_dst"]
     if "MSDA_HIP_LIB" not in os.environ:
         assert [k for k, n in enumerate(gotb) if n.startswith("exp:")] == [7]      # (round 4: the two-phase window backward)
         assert lib.msda_hip_set_variant(1, 7) != 0 and "experiment" in _lib.last_error()
-    for k in (8, 12, 99, -1):       # (slots 7..12 used to alias msda_bwd_tiled silently)
+    for k in (9, 12, 99, -1):       # (slots 7..12 used to alias msda_bwd_tiled silently)
         assert lib.msda_hip_set_variant(1, k) != 0 and lib.msda_hip_variant_name(1, k) is None
     assert lib.msda_hip_get_variant(1) == 0
     with pytest.raises(ValueError):

@@ -504,7 +504,8 @@ def test_fixed_point_grad_value_under_the_gradient_of_a_detection_loss(kernel, d
     assert e_a < 2e-4 and e_f < 1e-5
 
 
-@pytest.mark.parametrize("kernel,kind", [("msda_bwd_tiled", "encoder"), ("msda_bwd_win", "encoder"), ("msda_bwd_dec", "decoder")])
+@pytest.mark.parametrize("kernel,kind", [("msda_bwd_tiled", "encoder"), ("msda_bwd_win", "encoder"), ("msda_bwd_dec", "decoder"),
+                                         ("msda_bwd_dst", "decoder")])
 def test_fixed_point_backward_with_huge_upstream_gradients(kernel, kind, dev, api):
     """the scale exponent of the int32 LDS accumulators is clamped to [-90, 90]; a bound >= 2^121 (grad_output
     around 1e36) then scaled to 2^38 and wrapped silently.  Such tiles take the float-atomic path now: the result stays within
@@ -528,7 +529,7 @@ def test_fixed_point_backward_with_huge_upstream_gradients(kernel, kind, dev, ap
         assert rel < 1e-5, rel
 
 
-@pytest.mark.parametrize("kernel", ["msda_bwd_dec", "msda_bwd_generic"])
+@pytest.mark.parametrize("kernel", ["msda_bwd_dec", "msda_bwd_dst", "msda_bwd_generic"])
 def test_full_size_decoder_backward_every_query(kernel, dev, api):
     from oracle import msda_oracle
     from uninext_amd import workloads
@@ -772,18 +773,21 @@ DECODER_PYRAMIDS = [
 ]
 
 
+@pytest.mark.parametrize("kernel", ["msda_bwd_dec", "msda_bwd_dst"])
 @pytest.mark.parametrize("num_query", [64, 333, 1100])
 @pytest.mark.parametrize("levels", DECODER_PYRAMIDS)
-def test_decoder_backward_kernel_on_other_pyramids_and_query_counts(levels, num_query, dev, api):
+def test_decoder_backward_kernel_on_other_pyramids_and_query_counts(levels, num_query, kernel, dev, api):
     """msda_bwd_dec keeps whole rows of level 3, then level 2, in LDS accumulators and slices the queries over workgroups:
-    pyramids whose coarse levels do not fit, query counts that do not divide, every element against the oracle."""
+    pyramids whose coarse levels do not fit, query counts that do not divide, every element against the oracle.
+    msda_bwd_dst (round 6) cuts every level into 16 x 16 pixel tiles and slices the queries of the coarse ones: partial tiles,
+    one-row levels, slices that do not divide."""
     from oracle import msda_oracle
     from uninext_amd import workloads
     MSDA, lib = api
     x = workloads.make_inputs("decoder", "model", batch=3, levels=levels, num_query=num_query, heads=5, seed=81, device=dev)
     go = torch.randn(3, num_query, 160, generator=torch.Generator().manual_seed(82)).to(dev)
-    gv, gl, ga = _bwd(MSDA, lib, x, go, "msda_bwd_dec")
-    assert lib.last_kernel("backward") == "msda_bwd_dec"
+    gv, gl, ga = _bwd(MSDA, lib, x, go, kernel)
+    assert lib.last_kernel("backward") == kernel
     ogv, ogl, oga = msda_oracle.backward(go, x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
     tgv, _, tga = msda_oracle.backward(go.double(), x["value"].double(), x["shapes"], x["lsi"], x["loc"].double(), x["attn"].double())
     e_gv = float(np.abs(gv.cpu().numpy().astype(np.float64) - tgv).max())

@@ -394,6 +394,7 @@ int launch_backward<float>(int variant, const float* grad_out, const float* valu
   constexpr int kBwdWin = 4;            // backward variant 4: msda_bwd_win (value + gradient windows in LDS)
   constexpr int kBwdDec = 5;            // backward variant 5: msda_bwd_dec (decoder-style calls)
   constexpr int kBwdRegions = 6;        // backward variant 6: msda_bwd_regions (destination-side sums, no global atomics)
+  constexpr int kBwdDst = 8;            // backward variant 8: msda_bwd_dst (decoder-style calls, destination-side sums in LDS tiles; round 6)
   if (variant == kAuto) {
     // encoder-style calls: msda_bwd_win where the forward calls of the call site have reported near samples
     // (backward_site_choice, msda_fwd_win.hip), msda_bwd_tiled otherwise; generic for everything else
@@ -407,6 +408,11 @@ int launch_backward<float>(int variant, const float* grad_out, const float* valu
     }
   }
   drop_call_context();
+  if (variant == kBwdDst && dst_backward_ok(d)) {
+    *kernel_name = "msda_bwd_dst";
+    return launch_backward_dst(grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, stream);
+  }
+  if (variant == kBwdDst) variant = dec_backward_ok(d) ? kBwdDec : kGeneric;
   if (variant == kBwdDec && dec_backward_ok(d)) {
     *kernel_name = "msda_bwd_dec";
     return launch_backward_dec(grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, stream);

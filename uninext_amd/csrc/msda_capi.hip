@@ -27,13 +27,13 @@ constexpr bool kHaveExperiments = true;
 #define MSDA_EXP(name) "exp:" name
 constexpr bool kHaveExperiments = false;
 #endif
-constexpr int kNumFwdVariants = msda::kNumVariants, kNumBwdVariants = 8;
+constexpr int kNumFwdVariants = msda::kNumVariants, kNumBwdVariants = 9;
 const char* const kFwdNames[kNumFwdVariants] = {
     "auto", "msda_fwd_generic", "msda_fwd_lanegroup", MSDA_EXP("msda_fwd_tiled"), MSDA_EXP("msda_fwd_tiled_l0"),
     MSDA_EXP("msda_fwd_tiled_l0big"), MSDA_EXP("msda_fwd_lgcl"), "msda_fwd_lg3", MSDA_EXP("msda_fwd_lgp"), "msda_fwd_win",
     MSDA_EXP("msda_fwd_win2"), MSDA_EXP("msda_fwd_win3"), MSDA_EXP("msda_fwd_win4"), MSDA_EXP("msda_fwd_winl"), MSDA_EXP("msda_fwd_winp")};
 const char* const kBwdNames[kNumBwdVariants] = {"auto", "msda_bwd_generic", "msda_bwd_lanegroup", "msda_bwd_tiled",
-                                                "msda_bwd_win", "msda_bwd_dec", "msda_bwd_regions", MSDA_EXP("msda_bwd_win2")};
+                                                "msda_bwd_win", "msda_bwd_dec", "msda_bwd_regions", MSDA_EXP("msda_bwd_win2"), "msda_bwd_dst"};
 #undef MSDA_EXP
 
 int num_variants(int which) { return which == 0 ? kNumFwdVariants : kNumBwdVariants; }

@@ -154,6 +154,11 @@ int launch_backward_dec(const float* grad_out, const float* value, const int64_t
 int launch_backward_win(const float* grad_out, const float* value, const int64_t* shapes, const int64_t* lsi,
                         const float* loc, const float* attn, const Dims& d, float* grad_value, float* grad_loc,
                         float* grad_attn, hipStream_t stream);
+// msda_bwd_dst.hip (round 6): decoder-style calls with grad_value summed on the destination side (a workgroup owns a 16 x 16 pixel tile
+// of one level; float64 sums in LDS; no L2 atomics but the slice sums of the coarse levels)
+bool dst_backward_ok(const Dims& d);
+int launch_backward_dst(const float* grad_out, const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc,
+                        const float* attn, const Dims& d, float* grad_value, float* grad_loc, float* grad_attn, hipStream_t stream);
 
 // msda_fwd_win.hip: encoder forward with LDS windows on all four levels (fp32, D = 32, L = P = 4, Lq == S).
 bool win_forward_ok(const Dims& d);
