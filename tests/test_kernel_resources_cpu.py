@@ -28,6 +28,8 @@ LIMITS = {
     # round 4: the lane-parallel prefetch of a pair's inputs keeps 9 values in scratch across the query loop's head; measured WITH
     # them: 80 us against 88 for the version without (profiles/r04_backward_decoder.txt)
     "msda_bwd_dec.hip": {"msda::msda_bwd_dec": (128, 36)},
+    # round 6: two 512-thread workgroups per CU = 4 waves per SIMD; the loads of 5 scan steps / 5 record pairs travel together
+    "msda_bwd_dst.hip": {"msda::msda_bwd_dst": (128, 0)},
 }
 
 

@@ -800,6 +800,53 @@ def test_decoder_backward_kernel_on_other_pyramids_and_query_counts(levels, num_
         assert float(d_gl[:, :, :, l].max()) < 1e-4 * max(h, w, 10), (l, float(d_gl[:, :, :, l].max()))
 
 
+def test_destination_side_decoder_backward_under_capture_and_on_two_streams(dev, api):
+    """msda_bwd_dst draws its work slots from a per-launch counter (a ring of 64 in device memory, zeroed again by the launch's
+    last draw) and deals them out by stride under a stream capture, where replays could share a counter: both forms and an
+    eager call give the same gradients (grad_value up to the order of its float64 / float sums), a captured graph replays, and
+    launches that overlap on two streams do not disturb each other's counters."""
+    from uninext_amd import workloads
+    MSDA, lib = api
+    x = workloads.make_inputs("decoder", "model", batch=2, levels=workloads.R50_LEVELS_TRAIN, num_query=1100, seed=91, device=dev)
+    y = workloads.make_inputs("decoder", "uniform", batch=2, levels=workloads.R50_LEVELS_TRAIN, num_query=1100, seed=92, device=dev)
+    go = torch.randn(2, 1100, 256, generator=torch.Generator().manual_seed(93)).to(dev)
+    want_x = _bwd(MSDA, lib, x, go, "msda_bwd_dst")
+    want_y = _bwd(MSDA, lib, y, go, "msda_bwd_dst")
+    assert lib.last_kernel("backward") == "msda_bwd_dst"
+    scale = float(want_x[0].abs().max())
+    # stream capture: the strided deal
+    lib.set_variant("backward", "msda_bwd_dst")
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            MSDA.ms_deform_attn_backward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], go, 64)   # (first use outside the capture)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            got = MSDA.ms_deform_attn_backward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], go, 64)
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        assert float((got[0] - want_x[0]).abs().max()) < 1e-5 * scale
+        assert torch.equal(got[1], want_x[1]) and torch.equal(got[2], want_x[2])
+        # two streams, launches interleaved: each keeps its own counter
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        outs = []
+        for r in range(6):
+            with torch.cuda.stream(s1):
+                a = MSDA.ms_deform_attn_backward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], go, 64)
+            with torch.cuda.stream(s2):
+                b = MSDA.ms_deform_attn_backward(y["value"], y["shapes"], y["lsi"], y["loc"], y["attn"], go, 64)
+            outs.append((a, b))
+        torch.cuda.synchronize()
+        for a, b in outs:
+            assert float((a[0] - want_x[0]).abs().max()) < 1e-5 * scale and torch.equal(a[1], want_x[1]) and torch.equal(a[2], want_x[2])
+            assert float((b[0] - want_y[0]).abs().max()) < 1e-5 * scale and torch.equal(b[1], want_y[1]) and torch.equal(b[2], want_y[2])
+    finally:
+        lib.set_variant("backward", "auto")
+
+
 def test_decoder_backward_kernel_bounds_the_queries_of_a_slice(dev, api):
     """The fixed-point step of msda_bwd_dec rests on <= 256 queries per (image, head, slice): a call with more than 16 x 256
     queries gets more slices (every element against the oracle), one with more than 64 x 256 takes msda_bwd_generic even when

@@ -16,7 +16,7 @@ cat $O/trace_noextras.json >> $O/bench_kernel_trace_noextras.txt
 ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace_full -- python $R/bench.py --no-cpu-baseline --extras-only flavours,backward,train > $O/trace_full.json 2> $O/trace_full.err )
 python tools/rocprof_summary.py trace $(find $O/trace_full -name "*_results.db" | head -1) > $O/bench_kernel_trace.txt 2>&1
 cat $O/trace_full.json >> $O/bench_kernel_trace.txt
-timeout 600 python tools/kbench.py --reps 18 --rotate 6 --variants-fwd 7,9 --variants-bwd 3,4,5,6 --flavours model,wide,uniform > $O/kbench_final.txt 2>&1
+timeout 600 python tools/kbench.py --reps 18 --rotate 6 --variants-fwd 7,9 --variants-bwd 3,4,5,6,8 --flavours model,wide,uniform > $O/kbench_final.txt 2>&1
 timeout 900 python tools/kbench.py --reps 12 --rotate 3 --workloads all --flavours model,wide > $O/kbench_workloads.txt 2>&1
 timeout 200 python tools/ota_bench.py > $O/ota_bench.txt 2>&1
 # round 5: the dynamic mask head under autograd (time / peak memory against the PyTorch composition), the option-A stand-in
@@ -29,5 +29,7 @@ if [ -f uninext_amd/lib/libmsda_hip_exp.so ]; then
   done
 fi
 timeout 200 python tools/module_bench.py --reps 30 --rotate 3 > $O/module_bench.txt 2>&1
+# round 6: the static mask head in exact fp32, own MFMA convolution against MIOpen
+timeout 200 python tools/maskhead_exact_ab.py > $O/maskhead_exact_ab.txt 2>&1
 rm -rf $O/trace_noextras $O/trace_full $O/traffic_prof
 ls -la $O

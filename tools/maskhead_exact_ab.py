@@ -63,14 +63,13 @@ def main():
                   % (name, sorted(to)[len(to) // 2], min(to), eo, sorted(tm)[len(tm) // 2], min(tm), em))
         head = mask_head.MaskHeadSmallConv(256, None, 256).to(dev).eval()
         xs = [torch.randn(2, 256, h, w, device=dev) for h, w in ((100, 167), (50, 84), (25, 42))]
-        mask_head.MaskHeadSmallConv.exact_fp32 = True
-        lib_route = mask_head.conv3x3_relu
+        head.exact_fp32 = True
         to, tm = [], []
         for _ in range(args.rounds):
-            mask_head.conv3x3_relu = own_conv3x3_relu
+            head.own_exact_conv = True                 # conv3x3_hip_packed_exact_f32 on every layer
             to.append(timeit(lambda: head(xs, None), args.reps))
             y_own = head(xs, None)
-            mask_head.conv3x3_relu = lib_route
+            head.own_exact_conv = False                # the default: MIOpen
             tm.append(timeit(lambda: head(xs, None), args.reps))
             y_lib = head(xs, None)
         d = float((y_own - y_lib).abs().max()) / float(y_lib.abs().max())

@@ -180,8 +180,8 @@ def conv3x3_relu(x, conv, exact=True, own_exact=False):
     """`F.relu(conv(x))` for a 3x3 / padding 1 nn.Conv2d.
     exact=True (default): fp32 arithmetic as in the reference, through the PyTorch-ROCm / MIOpen convolution (~740 us for the
     head's module forward at bs 2).  own_exact=True: the same through this library's own exact-fp32 MFMA convolution
-    (conv3x3_hip_packed_exact_f32, include/conv3x3_hip.h; cached packed weights; inference only) -- round 6: 744 us for the module
-    against MIOpen's 738 on one box (faster on lay3 / lay4 / lay1, 3 % behind on the 256 -> 256 layer at 100 x 167:
+    (conv3x3_hip_packed_exact_f32, include/conv3x3_hip.h; cached packed weights; inference only) -- round 6: 733-744 us for the module
+    against MIOpen's 737-740 over four boxes (faster on lay3 / lay4 / lay1, 0-3 % behind on the 256 -> 256 layer at 100 x 167:
     profiles/r06_conv3x3_exact.txt), a tie that does not justify changing the default; round 5 had withdrawn it at 929-939 us.
     exact=False opts into the split-bf16 MFMA kernels of include/conv3x3_hip.h from cached packed weights (~390 us, ~2e-5 of
     the output scale, inside the 1e-4 parity bound); layers they do not take (input channels not a multiple of 16) go
