@@ -41,7 +41,7 @@ namespace {
 
 constexpr int kDstThreads = 512, kDstWaves = kDstThreads / 64;
 constexpr int kDstTile = 16, kDstTilePx = kDstTile * kDstTile;
-constexpr int kDstRecCap = 80;                                       // records per wave list; a list is worked off when a step might overflow it
+constexpr int kDstRecCap = 96;                                       // records per wave list; a list is worked off when a step would overflow it
 #ifndef DST_SCAN
 #define DST_SCAN 5
 #endif
@@ -55,7 +55,7 @@ constexpr int kDstTargetRecords = DST_TARGET, kDstMaxSlices = 16;
 constexpr int kDstScan = DST_SCAN;                                          // scan steps whose loads travel together
 constexpr int kDstBatch = DST_BATCH;                                         // pairs of records whose loads travel together
 constexpr int kDstAccBytes = kDstTilePx * 32 * 8;                    // 64 KB
-constexpr int kDstRecBytes = kDstWaves * kDstRecCap * 6 * 4;         // 15 KB
+constexpr int kDstRecBytes = kDstWaves * kDstRecCap * 5 * 4;         // 15 KB
 constexpr int kDstLds = kDstAccBytes + kDstRecBytes + 16;
 static_assert(kDstLds <= 80 * 1024, "two workgroups per CU");
 
@@ -86,13 +86,12 @@ msda_bwd_dst(const float* __restrict__ grad_out, const float* __restrict__ value
   int* const s_next = reinterpret_cast<int*>(smem + kDstAccBytes + kDstRecBytes);   // the workgroup's next slot
   const int tid = threadIdx.x, lane = tid & 63, ln = lane & 31, half = lane >> 5;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int* const rec = reinterpret_cast<int*>(smem + kDstAccBytes) + wv * (kDstRecCap * 6);   // this wave's list: six arrays of kDstRecCap
+  int* const rec = reinterpret_cast<int*>(smem + kDstAccBytes) + wv * (kDstRecCap * 5);   // this wave's list: five arrays of kDstRecCap
   int* const rA = rec;
   int* const rH = rec + kDstRecCap;
   int* const rW = rec + 2 * kDstRecCap;
   float* const rLh = reinterpret_cast<float*>(rec + 3 * kDstRecCap);
   float* const rLw = reinterpret_cast<float*>(rec + 4 * kDstRecCap);
-  float* const rAt = reinterpret_cast<float*>(rec + 5 * kDstRecCap);
   const int M = d.M, NM = d.N * d.M;
 
   // ---- the launch's slots, from the shape tensors (uniform: scalar loads) ----------------------------------------------------
@@ -155,7 +154,7 @@ msda_bwd_dst(const float* __restrict__ grad_out, const float* __restrict__ value
     auto process = [&](int cnt) __attribute__((always_inline)) {
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");            // the list's writes (this wave's own) are behind us
       for (int r0 = 0; r0 < cnt; r0 += 2 * kDstBatch) {
-        float g[kDstBatch], v[kDstBatch][4];
+        float g[kDstBatch], at_[kDstBatch], v[kDstBatch][4];
 #pragma unroll
         for (int k = 0; k < kDstBatch; ++k) {
           const int r = r0 + 2 * k + half;
@@ -164,6 +163,7 @@ msda_bwd_dst(const float* __restrict__ grad_out, const float* __restrict__ value
           const int a = rA[rr], hlo = rH[rr], wlo = rW[rr];
           const bool own = live && (a & kOwner) != 0;
           g[k] = live ? go_s[(int64_t)(a >> 8) * (M * 32) + ln] : 0.f;
+          at_[k] = live ? attn_s[(int64_t)(a >> 8) * (M * 16) + ((a >> 5) & 3)] : 0.f;   // (the weight travels with the gradient: the scan does not touch attn_weight)
           // (all in 32-bit arithmetic: with h_low or w_low = -1 the top-left offset wraps and its neighbours wrap back)
           const uint32_t ob = (lvl_off + (uint32_t)(hlo * Wl + wlo) * ps32 + (uint32_t)ln) * 4u;
           const bool tp = hlo >= 0, bt = hlo + 1 <= Hl - 1, lf = wlo >= 0, rt = wlo + 1 <= Wl - 1;   // (make_sample's rule)
@@ -180,7 +180,7 @@ msda_bwd_dst(const float* __restrict__ grad_out, const float* __restrict__ value
           const bool live = r < cnt;
           const int rr = live ? r : r0;
           const int a = rA[rr], hlo = rH[rr], wlo = rW[rr];
-          const float lh = rLh[rr], lw = rLw[rr], at = rAt[rr];
+          const float lh = rLh[rr], lw = rLw[rr], at = at_[k];
           const int flags = live ? (a & 31) : 0, p = (a >> 5) & 3, ql = a >> 8;
           const float hh = 1.f - lh, hw_ = 1.f - lw;
           const float w1 = hh * hw_, w2 = hh * lw, w3 = lh * hw_, w4 = lh * lw;
@@ -235,46 +235,62 @@ msda_bwd_dst(const float* __restrict__ grad_out, const float* __restrict__ value
     int cnt = 0;
     const float fy0 = (float)(y0 - 1), fy1 = (float)(y0 + kDstTile), fx0 = (float)(x0 - 1), fx1 = (float)(x0 + kDstTile);
     const float fH = (float)Hl, fW = (float)Wl;
-    for (int base = wv * 64; base < ns; base += kDstThreads * kDstScan) {
-      float sx[kDstScan], sy[kDstScan], sa[kDstScan];
+    // A batch = kDstScan steps whose loads travel together; its steps append while the list has room.  A step that might overflow the
+    // list stops the walk: the list is worked off at ONE place below (the body of process() is long; inlined once per step and once
+    // behind the loop it cost 23 spilled registers), the batch is loaded again (its registers are not kept across process()) and the walk
+    // resumes at that step.  The same place works off what is left after the last batch.
+    int base = wv * 64, start = 0;
+    bool more = true;
+    while (more) {
+      bool full = false;
+      if (base < ns) {
+        float sx[kDstScan], sy[kDstScan];
 #pragma unroll
-      for (int k = 0; k < kDstScan; ++k) {
-        const int s = base + k * kDstThreads + lane;
-        sx[k] = sy[k] = __builtin_nanf(""); sa[k] = 0.f;                 // (past the end: never a candidate)
-        if (s < ns) {
-          const int64_t qo = (int64_t)(s >> 2) * M;
-          const f32x2 xy = *reinterpret_cast<const f32x2*>(loc_s + qo * 32 + (s & 3) * 2);
-          sx[k] = xy[0]; sy[k] = xy[1];
-          sa[k] = attn_s[qo * 16 + (s & 3)];
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < kDstScan; ++k) {
-        if (base + k * kDstThreads >= ns) break;                         // (wave-uniform)
-        const int s = base + k * kDstThreads + lane;
-        const float h_im = sy[k] * fH - 0.5f, w_im = sx[k] * fW - 0.5f;  // (make_sample's expressions)
-        if (tile == 0) {                                                 // (uniform) samples outside the level: zero gradients, written by the level's first tile
-          const bool in_range = (h_im > -1.f) && (w_im > -1.f) && (h_im < fH) && (w_im < fW);
-          if (s < ns && !in_range) {
+        for (int k = 0; k < kDstScan; ++k) {
+          const int s = base + k * kDstThreads + lane;
+          sx[k] = sy[k] = __builtin_nanf("");                            // (past the end: never a candidate)
+          if (s < ns) {
             const int64_t qo = (int64_t)(s >> 2) * M;
-            ga_s[qo * 16 + (s & 3)] = 0.f;
-            *reinterpret_cast<f32x2*>(gl_s + qo * 32 + (s & 3) * 2) = f32x2{0.f, 0.f};
+            const f32x2 xy = *reinterpret_cast<const f32x2*>(loc_s + qo * 32 + (s & 3) * 2);
+            sx[k] = xy[0]; sy[k] = xy[1];
           }
         }
-        const bool match = (h_im >= fy0) && (h_im < fy1) && (w_im >= fx0) && (w_im < fx1);
-        const unsigned long long mask = __ballot(match);
-        if (mask) {
-          if (match) {
-            const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-            rA[pos] = s; rLh[pos] = sx[k]; rLw[pos] = sy[k]; rAt[pos] = sa[k];
+#pragma unroll
+        for (int k = 0; k < kDstScan; ++k) {
+          if (k >= start && !full && base + k * kDstThreads < ns) {      // (wave-uniform)
+            const int s = base + k * kDstThreads + lane;
+            const float h_im = sy[k] * fH - 0.5f, w_im = sx[k] * fW - 0.5f;  // (make_sample's expressions)
+            if (tile == 0) {                                             // (uniform) samples outside the level: zero gradients, written by the level's first tile
+              const bool in_range = (h_im > -1.f) && (w_im > -1.f) && (h_im < fH) && (w_im < fW);
+              if (s < ns && !in_range) {
+                const int64_t qo = (int64_t)(s >> 2) * M;
+                ga_s[qo * 16 + (s & 3)] = 0.f;
+                *reinterpret_cast<f32x2*>(gl_s + qo * 32 + (s & 3) * 2) = f32x2{0.f, 0.f};
+              }
+            }
+            const bool match = (h_im >= fy0) && (h_im < fy1) && (w_im >= fx0) && (w_im < fx1);
+            const unsigned long long mask = __ballot(match);
+            if (mask) {
+              const int n = __builtin_popcountll(mask);
+              if (cnt + n > kDstRecCap) {
+                full = true;
+                start = k;
+              } else {
+                if (match) {
+                  const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                  rA[pos] = s; rLh[pos] = sx[k]; rLw[pos] = sy[k];
+                }
+                cnt += n;
+              }
+            }
           }
-          cnt += __builtin_popcountll(mask);
-          if (cnt > kDstRecCap - 64) { refine(cnt); process(cnt); cnt = 0; }
         }
+        if (!full) { base += kDstThreads * kDstScan; start = 0; }
+      } else {
+        more = false;
       }
+      if (full || (!more && cnt > 0)) { refine(cnt); process(cnt); cnt = 0; }
     }
-    if (cnt) refine(cnt);
-    if (cnt) process(cnt);
     __syncthreads();
 
     // ---- flush: a half wave per pixel of the tile, sixteen pixels each: read and CLEAR the sums, then all reads of grad_value, then
