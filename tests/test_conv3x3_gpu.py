@@ -83,11 +83,12 @@ def test_full_size_r50_head(dev):
         head.exact_fp32 = False
         out = head(x, None)                                          # HIP route: split-bf16 from packed weights
         head.exact_fp32 = True
-        out_exact = head(x, None)                                    # the default: fp32 through MIOpen
-        head.own_exact_conv = True
-        out_own = head(x, None)                                      # exact fp32 through conv3x3_hip_packed_exact_f32 (round 6: opt-in)
+        assert head.own_exact_conv is True                           # the default since round 6
+        out_own = head(x, None)                                      # the default: exact fp32 through conv3x3_hip_packed_exact_f32
         assert torch.equal(head(x, None), out_own)                   # one fixed summation order: bitwise repeatable
         head.own_exact_conv = False
+        out_exact = head(x, None)                                    # fp32 through MIOpen
+        head.own_exact_conv = True
         F = torch.nn.functional
         f = F.relu(head.lay3(x[-1]))
         f = F.relu(head.lay4(x[-2] + F.interpolate(f, size=x[-2].shape[-2:], mode="nearest")))

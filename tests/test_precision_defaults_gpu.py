@@ -86,7 +86,7 @@ def test_mask_head_at_trained_scales(exact, dev):
         want = head.double()([t.double() for t in x], None)
     head = head.float().to(dev)
     old = MaskHeadSmallConv.exact_fp32
-    # True: the default -- fp32 through the MIOpen convolutions; False: split-bf16 (this library's MFMA kernels)
+    # True: the default -- exact fp32 (since round 6 through this library's own MFMA convolution); False: split-bf16
     MaskHeadSmallConv.exact_fp32 = bool(exact)
     try:
         with torch.no_grad():
@@ -96,7 +96,7 @@ def test_mask_head_at_trained_scales(exact, dev):
     scale = float(want.abs().max())
     err = float((got.double().cpu() - want).abs().max())
     print("MaskHeadSmallConv %s: max |err| %.3e = %.2e of the output scale %.1f" % (
-        {True: "fp32 (default, MIOpen)", False: "split-bf16"}[exact], err, err / scale, scale))
+        {True: "fp32 (default: own exact MFMA convolution)", False: "split-bf16"}[exact], err, err / scale, scale))
     assert err < (1e-5 if exact else 1e-4) * scale, (err, scale)
 
 

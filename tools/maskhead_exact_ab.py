@@ -66,10 +66,10 @@ def main():
         head.exact_fp32 = True
         to, tm = [], []
         for _ in range(args.rounds):
-            head.own_exact_conv = True                 # conv3x3_hip_packed_exact_f32 on every layer
+            head.own_exact_conv = True                 # the default since round 6: conv3x3_hip_packed_exact_f32 on every layer
             to.append(timeit(lambda: head(xs, None), args.reps))
             y_own = head(xs, None)
-            head.own_exact_conv = False                # the default: MIOpen
+            head.own_exact_conv = False                # MIOpen
             tm.append(timeit(lambda: head(xs, None), args.reps))
             y_lib = head(xs, None)
         d = float((y_own - y_lib).abs().max()) / float(y_lib.abs().max())

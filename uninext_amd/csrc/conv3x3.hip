@@ -469,7 +469,11 @@ conv3x3_packed(const float* __restrict__ in, const uint32_t* __restrict__ packed
 //     order (the f32 MFMA is an exact FMA), so the result is bitwise repeatable and within fp32 round-off of any other order.
 // TH: rows of the pixel tile (8 or 4; 16 columns): smaller tiles = more, shorter work units -- at these sizes the kernel runs at
 // the matrix pipe's rate and what is left to lose is the balance of units over the 1024 SIMDs (profiles/r04_conv3x3_exact.txt)
-template <int TH, int TJ, bool RELU, int WM>
+// WIDE (round 6): the halo travels as 16-byte loads of FOUR pixels of one channel (raw buffer loads: a row's first / last load reaches
+// one pixel past the image and reads zeros or a neighbour that is masked out) instead of one dword per (pixel, channel): a thread
+// issues 2 vector-memory instructions per chunk instead of 8, and it is the COUNT that costs -- the timing-only build with two 16-byte
+// loads in place of the eight dwords was 5.8 % faster on the 256 -> 256 layer at 100 x 167 (profiles/r06_conv3x3_exact.txt, section 4).
+template <int TH, int TJ, bool RELU, int WM, bool WIDE = false>
 __global__ void __launch_bounds__(kThreads, 2)
 conv3x3_exact(const float* __restrict__ in, const float* __restrict__ packed, const float* __restrict__ bias, Geom g,
               int tiles_x, int tiles_per_image, int cout_pad, float* __restrict__ out) {
@@ -486,36 +490,91 @@ constexpr int CONV3X3_EXACT_PITCH = 20;
   const int n0 = blockIdx.y * (64 * TJ);
   const int HW = g.H * g.W;
 
-  // ---- halo staging: items (halo pixel, h); this thread owns items tid and tid + 256: eight channels 2 s + h each ---------
+  // ---- halo staging ---------------------------------------------------------------------------------------------------------
+  // narrow form: items (halo pixel, h); this thread owns items tid and tid + 256: eight channels 2 s + h each
   const float* h_ptr[2];
   bool h_ok[2], h_has[2];
   int h_px[2], h_half[2];
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int item = tid + r * kThreads;
-    h_has[r] = item < 2 * kHalo;
-    const int hp = item % kHalo;
-    h_px[r] = hp;
-    h_half[r] = (item / kHalo) & 1;
-    const int gy = ty0 - 1 + hp / kHaloW, gx = tx0 - 1 + hp % kHaloW;
-    h_ok[r] = h_has[r] && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
-    h_ptr[r] = in + ((int64_t)b * g.Cin + h_half[r]) * HW + (h_ok[r] ? gy * g.W + gx : 0);
-  }
   float h_reg[2][8];
+  // wide form: items (row of the halo, group of four columns, channel), channel fastest -- the 64 lanes of a wave write 16 channel
+  // positions x 4 column groups = 64 different LDS banks per ds_write_b32
+  constexpr int kGroups = (kHaloW + 3) / 4;                                  // 5: columns 0-3, .., 12-15, 16-17
+  constexpr int kWideItems = kChunk * (TH + 2) * kGroups, kWidePer = (kWideItems + kThreads - 1) / kThreads;
+  uint32_t w_off[kWidePer];                                                  // byte offset of the item's first pixel in chunk 0 (out of range: a row outside the image)
+  int w_dst[kWidePer];                                                       // float index of the item's first pixel in a halo buffer
+  unsigned w_ok[kWidePer];                                                   // bits 0..3: the column is inside the image; bits 4..7: the column exists in the halo
+  f32x4 w_reg[kWidePer];
+  __amdgpu_buffer_rsrc_t in_rsrc;
+  if constexpr (WIDE) {
+    in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)((uint32_t)g.B * (uint32_t)g.Cin * (uint32_t)HW * 4u), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < kWidePer; ++i) {
+      const int item = tid + i * kThreads;
+      const bool has = item < kWideItems;
+      const int c = item & (kChunk - 1), rg = item / kChunk, gq = rg % kGroups, r = rg / kGroups;
+      const int gy = ty0 - 1 + r, gx0 = tx0 - 1 + 4 * gq;
+      const bool row_ok = has && (unsigned)gy < (unsigned)g.H;
+      unsigned ok = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (has && 4 * gq + j < kHaloW) ok |= 16u << j;
+        if (row_ok && 4 * gq + j < kHaloW && (unsigned)(gx0 + j) < (unsigned)g.W) ok |= 1u << j;
+      }
+      // a tile at the image's left edge: the first group starts at column -1 -- one float in front of the row, in front of the TENSOR in
+      // the first row of all (an offset that wraps: the whole load would read zeros).  Such an item loads columns 0..3 and stores them one
+      // halo column to the right (bit 8; halo column 0 is zero, the row's column 3 is the next group's first)
+      const bool shl = gx0 < 0;
+      if (shl) ok |= 256u;
+      w_ok[i] = ok;
+      w_off[i] = row_ok ? ((uint32_t)((b * g.Cin + c) * g.H + gy) * (uint32_t)g.W + (uint32_t)(shl ? 0 : gx0)) * 4u : msda::kOobOffset;
+      w_dst[i] = (r * kHaloW + 4 * gq) * kPitch + 8 * (c & 1) + (c >> 1);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int item = tid + r * kThreads;
+      h_has[r] = item < 2 * kHalo;
+      const int hp = item % kHalo;
+      h_px[r] = hp;
+      h_half[r] = (item / kHalo) & 1;
+      const int gy = ty0 - 1 + hp / kHaloW, gx = tx0 - 1 + hp % kHaloW;
+      h_ok[r] = h_has[r] && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
+      h_ptr[r] = in + ((int64_t)b * g.Cin + h_half[r]) * HW + (h_ok[r] ? gy * g.W + gx : 0);
+    }
+  }
   auto load_halo = [&](int chunk) {
+    if constexpr (WIDE) {
+      const uint32_t co = (uint32_t)chunk * (uint32_t)(kChunk * 4) * (uint32_t)HW;
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+      for (int i = 0; i < kWidePer; ++i)
+        w_reg[i] = msda::buffer_load_f32x4(in_rsrc, w_off[i] == msda::kOobOffset ? msda::kOobOffset : w_off[i] + co, 0);
+    } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) h_reg[r][e] = h_ok[r] ? h_ptr[r][(int64_t)(chunk * kChunk + 2 * e) * HW] : 0.f;
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h_reg[r][e] = h_ok[r] ? h_ptr[r][(int64_t)(chunk * kChunk + 2 * e) * HW] : 0.f;
+    }
   };
   auto store_halo = [&](int buf) {
+    if constexpr (WIDE) {
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
-      if (h_has[r]) {
-        float* dst = &As[buf][h_px[r]][h_half[r] * 8];
-        *reinterpret_cast<f32x4*>(dst) = f32x4{h_reg[r][0], h_reg[r][1], h_reg[r][2], h_reg[r][3]};
-        *reinterpret_cast<f32x4*>(dst + 4) = f32x4{h_reg[r][4], h_reg[r][5], h_reg[r][6], h_reg[r][7]};
+      for (int i = 0; i < kWidePer; ++i) {
+        float* dst = &As[buf][0][0] + w_dst[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v = (w_ok[i] & 256u) ? (j ? w_reg[i][j ? j - 1 : 0] : 0.f) : w_reg[i][j];
+          if (w_ok[i] & (16u << j)) dst[j * kPitch] = (w_ok[i] & (1u << j)) ? v : 0.f;
+        }
       }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+        if (h_has[r]) {
+          float* dst = &As[buf][h_px[r]][h_half[r] * 8];
+          *reinterpret_cast<f32x4*>(dst) = f32x4{h_reg[r][0], h_reg[r][1], h_reg[r][2], h_reg[r][3]};
+          *reinterpret_cast<f32x4*>(dst + 4) = f32x4{h_reg[r][4], h_reg[r][5], h_reg[r][6], h_reg[r][7]};
+        }
+    }
   };
 
   // ---- MFMA fragments (as conv3x3_packed: weights are the first operand, so accumulator rows are channels) ----------------
@@ -822,21 +881,25 @@ int conv3x3_hip_packed_exact_f32(const float* in, const void* packed, const floa
   else if (tiles * ((cout + 63) / 64) >= 2048) unit = 2;
   if (forced >= 1 && forced <= 3) unit = forced;
   if (unit == 1 && cout <= 64) unit = 2;
-#define CONV3X3_EXACT_LAUNCH(TH, TJ, WM, GX, GY, TX, TPI)                                                                             \
+#define CONV3X3_EXACT_LAUNCH(TH, TJ, WM, WIDE, GX, GY, TX, TPI)                                                                       \
   do {                                                                                                                                  \
     dim3 grid((unsigned)(GX), (unsigned)(GY));                                                                                          \
-    if (relu) hipLaunchKernelGGL((conv3x3::conv3x3_exact<TH, TJ, true, WM>), grid, dim3(conv3x3::kThreads), 0, st, in, pk, bias, g, TX, TPI, cout_pad, out); \
-    else hipLaunchKernelGGL((conv3x3::conv3x3_exact<TH, TJ, false, WM>), grid, dim3(conv3x3::kThreads), 0, st, in, pk, bias, g, TX, TPI, cout_pad, out);     \
+    if (relu) hipLaunchKernelGGL((conv3x3::conv3x3_exact<TH, TJ, true, WM, WIDE>), grid, dim3(conv3x3::kThreads), 0, st, in, pk, bias, g, TX, TPI, cout_pad, out); \
+    else hipLaunchKernelGGL((conv3x3::conv3x3_exact<TH, TJ, false, WM, WIDE>), grid, dim3(conv3x3::kThreads), 0, st, in, pk, bias, g, TX, TPI, cout_pad, out);     \
   } while (0)
   if (unit == 1) {
-    CONV3X3_EXACT_LAUNCH(8, 2, 1, tiles, (cout + 127) / 128, tiles_x, tiles_x * tiles_y);
+    CONV3X3_EXACT_LAUNCH(8, 2, 1, false, tiles, (cout + 127) / 128, tiles_x, tiles_x * tiles_y);
   } else if (unit == 2) {
-    CONV3X3_EXACT_LAUNCH(8, 1, 2, tiles, (cout + 63) / 64, tiles_x, tiles_x * tiles_y);
+    CONV3X3_EXACT_LAUNCH(8, 1, 2, false, tiles, (cout + 63) / 64, tiles_x, tiles_x * tiles_y);
   } else {
     const int tiles_y4 = (height + 3) / 4;
     const long long tiles4 = (long long)batch * tiles_x * tiles_y4;
     if (tiles4 >= (1ll << 31)) return dynmask_set_error(CONV3X3_ERR_BAD_DIMS, "conv3x3: problem too large");
-    CONV3X3_EXACT_LAUNCH(4, 1, 2, tiles4, (cout + 63) / 64, tiles_x, tiles_x * tiles_y4);
+    // the halo as 16-byte raw buffer loads (32-bit byte offsets: inputs below 2 GiB); CONV3X3_EXACT_WIDE=0: one dword per load (A/B)
+    static const int wide_env = msda::ab_env_int("CONV3X3_EXACT_WIDE", 1);
+    const bool wide = wide_env != 0 && (long long)batch * cin * height * width * 4 < (1ll << 31);
+    if (wide) CONV3X3_EXACT_LAUNCH(4, 1, 2, true, tiles4, (cout + 63) / 64, tiles_x, tiles_x * tiles_y4);
+    else CONV3X3_EXACT_LAUNCH(4, 1, 2, false, tiles4, (cout + 63) / 64, tiles_x, tiles_x * tiles_y4);
   }
 #undef CONV3X3_EXACT_LAUNCH
   const hipError_t e = hipGetLastError();

@@ -176,13 +176,14 @@ def _hip_conv_ok(x, conv):
             and _ext.conv3x3_supported(x, conv.weight))
 
 
-def conv3x3_relu(x, conv, exact=True, own_exact=False):
+def conv3x3_relu(x, conv, exact=True, own_exact=True):
     """`F.relu(conv(x))` for a 3x3 / padding 1 nn.Conv2d.
-    exact=True (default): fp32 arithmetic as in the reference, through the PyTorch-ROCm / MIOpen convolution (~740 us for the
-    head's module forward at bs 2).  own_exact=True: the same through this library's own exact-fp32 MFMA convolution
-    (conv3x3_hip_packed_exact_f32, include/conv3x3_hip.h; cached packed weights; inference only) -- round 6: 733-744 us for the module
-    against MIOpen's 737-740 over four boxes (faster on lay3 / lay4 / lay1, 0-3 % behind on the 256 -> 256 layer at 100 x 167:
-    profiles/r06_conv3x3_exact.txt), a tie that does not justify changing the default; round 5 had withdrawn it at 929-939 us.
+    exact=True (default): fp32 arithmetic as in the reference.  own_exact=True (the default since round 6): through this library's
+    own exact-fp32 MFMA convolution (conv3x3_hip_packed_exact_f32, include/conv3x3_hip.h: halo tiles, v_mfma_f32_32x32x2_f32, one
+    fixed-order FMA chain per output -- bitwise repeatable; cached packed weights; inference only) -- 713 us for the head's module
+    forward at bs 2 against 743 us through MIOpen, ahead on every one of the five layers since the halo travels as 16-byte loads
+    (profiles/r06_conv3x3_exact.txt; round 5 had withdrawn the kernel at 929-939 us).  own_exact=False: the PyTorch-ROCm / MIOpen
+    convolution, which also takes whatever the kernel does not (input channels not a multiple of 16, autograd, CPU).
     exact=False opts into the split-bf16 MFMA kernels of include/conv3x3_hip.h from cached packed weights (~390 us, ~2e-5 of
     the output scale, inside the 1e-4 parity bound); layers they do not take (input channels not a multiple of 16) go
     through conv3x3_hip_f32.  Training, CPU, other dtypes or geometries: PyTorch."""
@@ -207,8 +208,9 @@ class MaskHeadSmallConv(CachedModuleMixin, torch.nn.Module):
     # True (default): the reference's fp32 arithmetic (MIOpen convolutions); False -- or env UNINEXT_AMD_SPLIT_BF16=1 -- opts
     # into the split-bf16 MFMA kernels (3 of 4 partial products, ~2e-5 of the output scale; the fast ones)
     exact_fp32 = os.environ.get("UNINEXT_AMD_SPLIT_BF16", "0") != "1"
-    # exact fp32 through this library's own MFMA convolution instead of MIOpen (a tie in round 6, see conv3x3_relu); inference only
-    own_exact_conv = False
+    # exact fp32 through this library's own MFMA convolution (default since round 6: 4 % ahead of MIOpen on the head, see conv3x3_relu);
+    # False: MIOpen.  Inference only either way: under autograd the convolutions are PyTorch's
+    own_exact_conv = True
 
     def __init__(self, dim, fpn_dims, context_dim, use_raft=False, up_rate=4):
         super().__init__()
