@@ -23,6 +23,11 @@ def dev():
     (1, 64, 100, 167, 8),      # lay2 of the R50 model (cout 8 -> 64 x 64 tiles)
     (2, 16, 100, 167, 130),    # 128 x 128 tiles (522 of them), partial channel tile, two images
     (3, 48, 9, 300, 130),      # wide rows, partial 128-channel tile
+    (2, 16, 6, 5, 8),          # round 6, the exact kernel's 16-byte halo loads: widths of every residue mod 4 -- a row's last load
+    (1, 32, 3, 2, 8),          # reaches past the row, in the tensor's last row past the tensor (read as zeros, masked) --,
+    (2, 16, 17, 18, 16),       # an image narrower than one load, exactly one halo wide, a single pixel
+    (1, 16, 1, 1, 8),
+    (1, 16, 4, 21, 8),
 ])
 @pytest.mark.parametrize("relu", [True, False])
 @pytest.mark.parametrize("precision", [0, 1, 2, 3])     # 2: the packed-weight fast path of precision 1; 3: the exact fp32 halo kernel
