@@ -56,6 +56,26 @@ def test_vs_oracle(B, C, H, W, E, relu, precision, dev):
     assert max_abs(out, conv3x3_oracle.conv3x3(x, w, None, relu)) < 1e-4 * max(1.0, float(np.abs(ref).max()))
 
 
+@pytest.mark.parametrize("B,C,H,W,E", [
+    (2, 16, 300, 470, 64),     # >= 2048 units of 8 x 16 x 64: the exact kernel's second unit (two sub-tiles per wave)
+    (2, 16, 200, 330, 130),    # ... and its first (8 x 16 x 128, partial channel tile)
+])
+def test_exact_kernel_larger_units(B, C, H, W, E, dev):
+    """conv3x3_hip_packed_exact_f32 picks 8 x 16 pixel units when a launch has >= 2048 of them (feature maps beyond the R50 head's):
+    the same kernel body with two sub-tiles per wave and, since round 6, the 16-byte halo loads -- against PyTorch's float64
+    convolution on the device (the numpy oracle takes minutes at these sizes)."""
+    from uninext_amd import ext
+    g = torch.Generator().manual_seed(C + E)
+    x = torch.randn(B, C, H, W, generator=g).to(dev)
+    w = (torch.randn(E, C, 3, 3, generator=g) / (9 * C) ** 0.5).to(dev)
+    b = torch.randn(E, generator=g).to(dev)
+    packed = ext.conv3x3_pack_weight(w, exact=True)
+    got = ext.conv3x3_packed_forward(x, packed, E, b, relu=True, exact=True)
+    want = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1))
+    assert float((got.double() - want).abs().max()) < 5e-6 * max(1.0, float(want.abs().max()))
+    assert torch.equal(got, ext.conv3x3_packed_forward(x, packed, E, b, relu=True, exact=True))
+
+
 @pytest.mark.parametrize("name", maskhead_names())
 def test_module_vs_reference_fixture(name, dev):
     from uninext_amd.mask_head import MaskHeadSmallConv

@@ -887,17 +887,19 @@ int conv3x3_hip_packed_exact_f32(const float* in, const void* packed, const floa
     if (relu) hipLaunchKernelGGL((conv3x3::conv3x3_exact<TH, TJ, true, WM, WIDE>), grid, dim3(conv3x3::kThreads), 0, st, in, pk, bias, g, TX, TPI, cout_pad, out); \
     else hipLaunchKernelGGL((conv3x3::conv3x3_exact<TH, TJ, false, WM, WIDE>), grid, dim3(conv3x3::kThreads), 0, st, in, pk, bias, g, TX, TPI, cout_pad, out);     \
   } while (0)
+  // the halo as 16-byte raw buffer loads (32-bit byte offsets: inputs below 2 GiB); CONV3X3_EXACT_WIDE=0: one dword per load (A/B)
+  static const int wide_env = msda::ab_env_int("CONV3X3_EXACT_WIDE", 1);
+  const bool wide = wide_env != 0 && (long long)batch * cin * height * width * 4 < (1ll << 31);
   if (unit == 1) {
-    CONV3X3_EXACT_LAUNCH(8, 2, 1, false, tiles, (cout + 127) / 128, tiles_x, tiles_x * tiles_y);
+    if (wide) CONV3X3_EXACT_LAUNCH(8, 2, 1, true, tiles, (cout + 127) / 128, tiles_x, tiles_x * tiles_y);
+    else CONV3X3_EXACT_LAUNCH(8, 2, 1, false, tiles, (cout + 127) / 128, tiles_x, tiles_x * tiles_y);
   } else if (unit == 2) {
-    CONV3X3_EXACT_LAUNCH(8, 1, 2, false, tiles, (cout + 63) / 64, tiles_x, tiles_x * tiles_y);
+    if (wide) CONV3X3_EXACT_LAUNCH(8, 1, 2, true, tiles, (cout + 63) / 64, tiles_x, tiles_x * tiles_y);
+    else CONV3X3_EXACT_LAUNCH(8, 1, 2, false, tiles, (cout + 63) / 64, tiles_x, tiles_x * tiles_y);
   } else {
     const int tiles_y4 = (height + 3) / 4;
     const long long tiles4 = (long long)batch * tiles_x * tiles_y4;
     if (tiles4 >= (1ll << 31)) return dynmask_set_error(CONV3X3_ERR_BAD_DIMS, "conv3x3: problem too large");
-    // the halo as 16-byte raw buffer loads (32-bit byte offsets: inputs below 2 GiB); CONV3X3_EXACT_WIDE=0: one dword per load (A/B)
-    static const int wide_env = msda::ab_env_int("CONV3X3_EXACT_WIDE", 1);
-    const bool wide = wide_env != 0 && (long long)batch * cin * height * width * 4 < (1ll << 31);
     if (wide) CONV3X3_EXACT_LAUNCH(4, 1, 2, true, tiles4, (cout + 63) / 64, tiles_x, tiles_x * tiles_y4);
     else CONV3X3_EXACT_LAUNCH(4, 1, 2, false, tiles4, (cout + 63) / 64, tiles_x, tiles_x * tiles_y4);
   }
