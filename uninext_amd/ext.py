@@ -91,7 +91,7 @@ class _AutoSites:
         self.shapes_ref = None            # weak reference to the spatial_shapes object of the current pass
         self.shapes_version = -1
         self.ordinal = 0
-        self.by_loc = {}                  # sampling_loc.data_ptr() -> site, insertion-ordered
+        self.by_loc = {}                  # (sampling_loc.data_ptr(), its shape) -> site, insertion-ordered
         self.last = -1                    # the site the last context carried (tests, bench)
         self.unmatched = 0                # backward calls whose forward was not found (they take the history-free kernel)
 
@@ -109,14 +109,16 @@ class _AutoSites:
             site = AUTO_SITE_BASE + self.ordinal % AUTO_SITES
             self.ordinal += 1
             if sampling_loc is not None:
-                self.by_loc[int(sampling_loc.data_ptr())] = site
+                # (address AND shape: the caching allocator hands a freed address out again -- an inference pass's leftover entry must
+                # not vouch for a later tensor of another call)
+                self.by_loc[(int(sampling_loc.data_ptr()), tuple(sampling_loc.shape))] = site
                 while len(self.by_loc) > _AUTO_BWD_KEEP:
                     self.by_loc.pop(next(iter(self.by_loc)))
             return site
 
     def backward(self, sampling_loc):
         with self.lock:
-            site = self.by_loc.pop(int(sampling_loc.data_ptr()), None)
+            site = self.by_loc.pop((int(sampling_loc.data_ptr()), tuple(sampling_loc.shape)), None)
             if site is None:
                 self.unmatched += 1
             return site
